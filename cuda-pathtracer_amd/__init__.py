@@ -1,0 +1,16 @@
+"""cuda-pathtracer_amd — MI355X-native replacement for the per-pixel path-tracing megakernel of
+DavidPeicho/cuda-pathtracer (raytrace() / setupFunctionTables(), cuda_opengl/include/shaders/raytrace.h).
+
+The product is libptamd.so (hand-written HIP for gfx950 behind the C-ABI of include/ptamd.h);
+this package is the thin host mirror of the reference interface.  The directory name
+carries a hyphen; import it as `cuda_pathtracer_amd` (alias module at the repo root).
+"""
+from . import native
+from .native import (KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, PtamdError)
+from .scene import (HostScene, cubemap_for_scene, cubemap_from_color, cubemap_from_cross,
+                    FACE_DTYPE, MATERIAL_DTYPE, LIGHT_DTYPE, TEXTURE_DTYPE, CAMERA_DTYPE)
+from .render import (Context, FrameRenderer, host_bvh_trace, wang_hash, REFERENCE_BOUNCES,
+                     POST_NONE, POST_GRAYSCALE, POST_SEPIA, POST_INVERT)
+from .tiles import row_bands, band_of_rank
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,17 @@
+// pt_launch.h — host-callable launchers of the device code in pt_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptamd {
+
+struct KParams;
+
+// kind: 1 brute force, 2 BVH.  lds_bytes: dynamic LDS needed when lds_resident.
+hipError_t launch_megakernel(const KParams& p, int kind, bool lds_resident, size_t lds_bytes, bool stats,
+                             hipStream_t stream);
+hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,
+                             hipStream_t stream);
+
+} // namespace ptamd

@@ -1,0 +1,454 @@
+// ptamd_api.cpp — the C-ABI of libptamd.so (include/ptamd.h): device context, scene and
+// cubemap upload, and the raytrace() replacement.
+//
+// Reference call path being replaced:
+//   GPUProcessor::render  -> raytrace(...)           cuda_opengl/src/gpu_processor.cpp:375-377
+//   raytrace()            -> kernel<<<...>>>(...)    cuda_opengl/src/shaders/raytrace.cu:287-325
+// The frame counter that raytrace.cu keeps in a function-static (:296-300) lives in the
+// context.  Pixel-invariant camera terms of generateRay (intersection.cuh:79-87) are
+// computed here once per launch with the same float operations the kernel would do.
+#include "../host/ptamd_internal.h"
+#include "pt_device.h"
+#include "pt_launch.h"
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+
+namespace ptamd {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+namespace {
+
+struct DeviceScene {
+  float4* nodes = nullptr;
+  float4* tris_bvh = nullptr;
+  float4* tris_brute = nullptr;
+  float4* shade = nullptr;
+  int4* materials = nullptr;
+  float4* lights = nullptr;
+  TexDesc* textures = nullptr;
+  float* texels = nullptr;
+  uint32_t n_faces = 0, n_lights = 0, n_nodes = 0, n_materials = 0, n_textures = 0;
+  ptamd_scene_info info{};
+};
+
+struct DeviceCubemap {
+  float4* faces = nullptr;
+  uint32_t size = 0;
+};
+
+} // namespace
+
+} // namespace ptamd
+
+struct ptamd_context {
+  int device = 0;
+  std::vector<ptamd::DeviceScene> scenes;
+  std::vector<ptamd::DeviceCubemap> cubemaps;
+  uint32_t frame_counter = 0; // raytrace.cu:296 `static unsigned int seed`
+  unsigned long long* d_stats = nullptr;
+};
+
+namespace ptamd {
+namespace {
+
+constexpr size_t kLdsBudget = 64 * 1024;
+constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
+constexpr uint32_t kMaxLeaf = 4;
+
+int hip_fail(const char* what, hipError_t e)
+{
+  set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return PTAMD_ERR_HIP;
+}
+
+#define PT_HIP(call)                                         \
+  do {                                                       \
+    hipError_t _e = (call);                                  \
+    if (_e != hipSuccess) return hip_fail(#call, _e);        \
+  } while (0)
+
+template <typename T>
+int upload(T*& dst, const void* src, size_t bytes)
+{
+  dst = nullptr;
+  if (bytes == 0) bytes = 16; // keep pointers valid for empty tables
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&dst), bytes));
+  if (src) PT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  else PT_HIP(hipMemset(dst, 0, bytes));
+  return PTAMD_OK;
+}
+
+void free_scene(DeviceScene& s)
+{
+  hipFree(s.nodes); hipFree(s.tris_bvh); hipFree(s.tris_brute); hipFree(s.shade);
+  hipFree(s.materials); hipFree(s.lights); hipFree(s.textures); hipFree(s.texels);
+  s = DeviceScene();
+}
+
+inline f3 hf3(ptamd_float3 v) { f3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
+inline f3 hadd(f3 a, f3 b) { f3 r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; return r; }
+inline f3 hmuls(f3 a, float s) { f3 r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; return r; }
+inline f3 hcross(f3 a, f3 b)
+{
+  f3 r;
+  r.x = a.y * b.z - a.z * b.y; r.y = a.z * b.x - a.x * b.z; r.z = a.x * b.y - a.y * b.x;
+  return r;
+}
+inline f3 hnormalize(f3 v)
+{
+  float inv_len = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+  return hmuls(v, inv_len);
+}
+
+int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
+{
+  if (!ctx || !l) { set_error("ptamd_raytrace: null context or launch"); return PTAMD_ERR_ARG; }
+  if (!l->surface_rgba8 || !l->temporal_framebuffer) { set_error("ptamd_raytrace: null output buffer"); return PTAMD_ERR_ARG; }
+  if (l->scene_id >= ctx->scenes.size()) { set_error("ptamd_raytrace: scene_id out of range"); return PTAMD_ERR_ARG; }
+  if (l->cubemap_id >= ctx->cubemaps.size()) { set_error("ptamd_raytrace: cubemap_id out of range"); return PTAMD_ERR_ARG; }
+  if (l->post_id > 3) { set_error("ptamd_raytrace: post_id out of range (0..3)"); return PTAMD_ERR_ARG; }
+  if (l->width == 0 || l->height == 0 || l->width > 65536 || l->height > 65536) { set_error("ptamd_raytrace: bad frame size"); return PTAMD_ERR_ARG; }
+  if (l->row_begin > l->row_end || l->row_end > l->height) { set_error("ptamd_raytrace: bad row band"); return PTAMD_ERR_ARG; }
+  if (l->frame_nb == 0) { set_error("ptamd_raytrace: frame_nb must be >= 1"); return PTAMD_ERR_ARG; }
+  if (l->bounces == 0 || l->bounces > 1024) { set_error("ptamd_raytrace: bounces out of range (1..1024)"); return PTAMD_ERR_ARG; }
+  if (l->kernel > PTAMD_KERNEL_BVH) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
+  return PTAMD_OK;
+}
+
+int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
+{
+  int rc = validate_launch(ctx, l);
+  if (rc != PTAMD_OK) return rc;
+  PT_HIP(hipSetDevice(ctx->device));
+  const DeviceScene& s = ctx->scenes[l->scene_id];
+  const DeviceCubemap& cm = ctx->cubemaps[l->cubemap_id];
+
+  KParams p;
+  std::memset(&p, 0, sizeof p);
+  p.nodes = s.nodes; p.tris_bvh = s.tris_bvh; p.tris_brute = s.tris_brute; p.shade = s.shade;
+  p.materials = s.materials; p.lights = s.lights; p.textures = s.textures; p.texels = s.texels;
+  p.cubemap = cm.faces; p.cubemap_size = cm.size;
+  p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes;
+
+  // generateRay's pixel-invariant part (intersection.cuh:79-89)
+  const ptamd_camera& cam = l->camera;
+  const int half_w = (int)(l->width / 2u);
+  const float screen_dist = (float)half_w / tanf(cam.fov_x * 0.5f);
+  f3 down; down.x = 0.0f; down.y = -1.0f; down.z = 0.0f;
+  f3 u = hnormalize(hcross(hf3(cam.dir), down));
+  f3 v = hnormalize(hcross(u, hf3(cam.dir)));
+  u = hmuls(u, -1.0f);
+  p.cam_pos = hf3(cam.position);
+  p.cam_p0 = hadd(hf3(cam.position), hmuls(hf3(cam.dir), screen_dist));
+  p.cam_u = u; p.cam_v = v;
+  p.focus_dist = cam.focus_dist; p.aperture = cam.aperture;
+
+  p.width = l->width; p.height = l->height; p.row_begin = l->row_begin; p.row_end = l->row_end;
+  p.hash_seed = ptamd_wang_hash(l->frame_nb);
+  p.frame_nb_f = (float)(int)l->frame_nb;
+  p.is_static = l->moved ? 0 : 1;
+  p.bounces = (int32_t)l->bounces;
+  p.post_id = l->post_id;
+  p.tfb = l->temporal_framebuffer;
+  p.surface = static_cast<uint32_t*>(l->surface_rgba8);
+  if (l->band_local_buffers) {
+    p.tfb_row0 = l->height - l->row_end; // band covers accumulator rows [H-row_end, H-row_begin)
+    p.surf_row0 = l->row_begin;
+  }
+  p.stats = stats ? ctx->d_stats : nullptr;
+
+  int kind = l->kernel == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2;
+  const size_t lds = kind == 1 ? s.info.lds_bytes_brute : s.info.lds_bytes_bvh;
+  const bool resident = lds <= kLdsBudget;
+  hipError_t e = launch_megakernel(p, kind, resident, lds, stats, static_cast<hipStream_t>(l->stream));
+  if (e != hipSuccess) return hip_fail("megakernel launch", e);
+  return PTAMD_OK;
+}
+
+} // namespace
+} // namespace ptamd
+
+using namespace ptamd;
+
+extern "C" {
+
+const char* ptamd_get_last_error(void) { return g_last_error.c_str(); }
+const char* ptamd_version(void) { return "ptamd 0.1 (gfx950)"; }
+
+uint32_t ptamd_wang_hash(uint32_t a)
+{
+  a = (a ^ 61u) ^ (a >> 16);
+  a = a + (a << 3);
+  a = a ^ (a >> 4);
+  a = a * 0x27d4eb2du;
+  a = a ^ (a >> 15);
+  return a;
+}
+
+int ptamd_create(int32_t device_ordinal, ptamd_context** out)
+{
+  if (!out) { set_error("ptamd_create: null out"); return PTAMD_ERR_ARG; }
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    set_error(std::string("ptamd_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+              "); this library has no CPU fallback");
+    return PTAMD_ERR_HIP;
+  }
+  if (device_ordinal < 0 || device_ordinal >= n) { set_error("ptamd_create: device ordinal out of range"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(device_ordinal));
+  std::unique_ptr<ptamd_context> ctx(new (std::nothrow) ptamd_context());
+  if (!ctx) { set_error("ptamd_create: out of memory"); return PTAMD_ERR_ARG; }
+  ctx->device = device_ordinal;
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), 8 * sizeof(unsigned long long)));
+  *out = ctx.release();
+  return PTAMD_OK;
+}
+
+void ptamd_destroy(ptamd_context* ctx)
+{
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  for (auto& s : ctx->scenes) free_scene(s);
+  for (auto& c : ctx->cubemaps) hipFree(c.faces);
+  hipFree(ctx->d_stats);
+  delete ctx;
+}
+
+int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t* out_scene_id)
+{
+  if (!ctx || !sc || !out_scene_id) { set_error("ptamd_upload_scene: null argument"); return PTAMD_ERR_ARG; }
+  if ((sc->n_faces && !sc->faces) || (sc->n_materials && !sc->materials) || (sc->n_lights && !sc->lights) ||
+      (sc->n_textures && !sc->textures) || (sc->n_texel_floats && !sc->texels) || (sc->n_meshes && !sc->mesh_sizes)) {
+    set_error("ptamd_upload_scene: null table with non-zero count");
+    return PTAMD_ERR_ARG;
+  }
+  uint64_t total = 0;
+  for (uint32_t m = 0; m < sc->n_meshes; ++m) total += sc->mesh_sizes[m];
+  if (total != sc->n_faces) { set_error("ptamd_upload_scene: mesh_sizes do not sum to n_faces"); return PTAMD_ERR_ARG; }
+  for (uint32_t i = 0; i < sc->n_faces; ++i)
+    if (sc->faces[i].material_id >= sc->n_materials) { set_error("ptamd_upload_scene: face material_id out of range"); return PTAMD_ERR_ARG; }
+  for (uint32_t i = 0; i < sc->n_textures; ++i) {
+    const ptamd_texture_desc& t = sc->textures[i];
+    if (t.w < 1 || t.h < 1 || t.nb_chan < 1 || t.offset + (uint64_t)t.w * t.h * t.nb_chan > sc->n_texel_floats) {
+      set_error("ptamd_upload_scene: texture descriptor out of the texel blob");
+      return PTAMD_ERR_ARG;
+    }
+  }
+  for (uint32_t i = 0; i < sc->n_materials; ++i) {
+    const ptamd_material& m = sc->materials[i];
+    if (m.diffuse_spec_map < 0 || (uint32_t)m.diffuse_spec_map >= sc->n_textures || sc->textures[m.diffuse_spec_map].nb_chan != 4 ||
+        (m.normal_map >= 0 && ((uint32_t)m.normal_map >= sc->n_textures || sc->textures[m.normal_map].nb_chan < 3))) {
+      set_error("ptamd_upload_scene: material texture id invalid (diffuse+spec must be 4-channel)");
+      return PTAMD_ERR_ARG;
+    }
+  }
+
+  Bvh bvh;
+  int rc = build_bvh(sc->faces, sc->n_faces, kBoxMargin, kMaxLeaf, bvh);
+  if (rc != PTAMD_OK) return rc;
+
+  // storage-order {v0,e1,e2,idx} records for the brute-force variant, and the shading records
+  std::vector<float> brute((size_t)sc->n_faces * 12, 0.0f), shade((size_t)sc->n_faces * 20, 0.0f);
+  for (uint32_t i = 0; i < sc->n_faces; ++i) {
+    const ptamd_face& f = sc->faces[i];
+    float* t = &brute[(size_t)i * 12];
+    t[0] = f.vertices[0].x; t[1] = f.vertices[0].y; t[2] = f.vertices[0].z;
+    t[3] = f.vertices[1].x - f.vertices[0].x; t[4] = f.vertices[1].y - f.vertices[0].y; t[5] = f.vertices[1].z - f.vertices[0].z;
+    t[6] = f.vertices[2].x - f.vertices[0].x; t[7] = f.vertices[2].y - f.vertices[0].y; t[8] = f.vertices[2].z - f.vertices[0].z;
+    std::memcpy(&t[9], &i, 4);
+    float* s = &shade[(size_t)i * 20];
+    std::memcpy(s, f.normals, 36);
+    std::memcpy(s + 9, f.texcoords, 24);
+    std::memcpy(s + 15, &f.tangent, 12);
+    std::memcpy(s + 18, &f.material_id, 4);
+  }
+  std::vector<int32_t> mats((size_t)sc->n_materials * 4, 0);
+  for (uint32_t i = 0; i < sc->n_materials; ++i) {
+    mats[i * 4 + 0] = sc->materials[i].diffuse_spec_map;
+    mats[i * 4 + 1] = sc->materials[i].normal_map;
+    std::memcpy(&mats[i * 4 + 2], &sc->materials[i].ior, 4);
+  }
+  std::vector<TexDesc> tex(sc->n_textures);
+  for (uint32_t i = 0; i < sc->n_textures; ++i) {
+    tex[i].w = sc->textures[i].w; tex[i].h = sc->textures[i].h; tex[i].nb_chan = sc->textures[i].nb_chan;
+    tex[i].pad = 0; tex[i].offset = sc->textures[i].offset;
+  }
+
+  PT_HIP(hipSetDevice(ctx->device));
+  DeviceScene d;
+  d.n_faces = sc->n_faces; d.n_lights = sc->n_lights; d.n_nodes = bvh.n_nodes;
+  d.n_materials = sc->n_materials; d.n_textures = sc->n_textures;
+  if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
+      (rc = upload(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4)) ||
+      (rc = upload(d.tris_brute, brute.data(), brute.size() * 4)) ||
+      (rc = upload(d.shade, shade.data(), shade.size() * 4)) ||
+      (rc = upload(d.materials, mats.data(), mats.size() * 4)) ||
+      (rc = upload(d.lights, sc->lights, (size_t)sc->n_lights * sizeof(ptamd_light))) ||
+      (rc = upload(d.textures, tex.data(), tex.size() * sizeof(TexDesc))) ||
+      (rc = upload(d.texels, sc->texels, (size_t)sc->n_texel_floats * 4))) {
+    free_scene(d);
+    return rc;
+  }
+  d.info.n_faces = sc->n_faces; d.info.n_lights = sc->n_lights; d.info.n_nodes = bvh.n_nodes;
+  d.info.n_leaves = bvh.n_leaves; d.info.max_leaf_size = bvh.max_leaf; d.info.depth = bvh.depth;
+  d.info.node_bytes = 64; d.info.tri_bytes = 48;
+  d.info.lds_bytes_bvh = bvh.n_nodes * 64u + sc->n_faces * 48u;
+  d.info.lds_bytes_brute = sc->n_faces * 48u;
+  ctx->scenes.push_back(d);
+  *out_scene_id = (uint32_t)ctx->scenes.size() - 1;
+  return PTAMD_OK;
+}
+
+int ptamd_upload_cubemap(ptamd_context* ctx, const float* faces, uint32_t size, uint32_t* out_cubemap_id)
+{
+  if (!ctx || !faces || !out_cubemap_id || size == 0 || size > 16384) { set_error("ptamd_upload_cubemap: bad argument"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  DeviceCubemap c;
+  c.size = size;
+  int rc = upload(c.faces, faces, (size_t)6 * size * size * 16);
+  if (rc != PTAMD_OK) return rc;
+  ctx->cubemaps.push_back(c);
+  *out_cubemap_id = (uint32_t)ctx->cubemaps.size() - 1;
+  return PTAMD_OK;
+}
+
+int ptamd_setup_function_tables(ptamd_context* ctx)
+{
+  if (!ctx) { set_error("ptamd_setup_function_tables: null context"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  return PTAMD_OK;
+}
+
+int ptamd_reset_frame_counter(ptamd_context* ctx)
+{
+  if (!ctx) { set_error("ptamd_reset_frame_counter: null context"); return PTAMD_ERR_ARG; }
+  ctx->frame_counter = 0;
+  return PTAMD_OK;
+}
+
+int ptamd_raytrace(ptamd_context* ctx, void* surface_rgba8, uint32_t scene_id, uint32_t cubemap_id,
+                   const ptamd_camera* cam, uint32_t width, uint32_t height, void* stream,
+                   float* temporal_framebuffer, int32_t moved, uint32_t post_id)
+{
+  if (!ctx || !cam) { set_error("ptamd_raytrace: null argument"); return PTAMD_ERR_ARG; }
+  // raytrace.cu:296-300
+  uint32_t seed = ctx->frame_counter;
+  if (moved) seed = 0;
+  seed++;
+  ptamd_launch l;
+  std::memset(&l, 0, sizeof l);
+  l.surface_rgba8 = surface_rgba8; l.temporal_framebuffer = temporal_framebuffer; l.stream = stream;
+  l.camera = *cam; l.scene_id = scene_id; l.cubemap_id = cubemap_id;
+  l.width = width; l.height = height; l.row_begin = 0; l.row_end = height;
+  l.frame_nb = seed; l.bounces = 3; /* static_samples = 1 (raytrace.cu:243,66) */
+  l.moved = moved; l.post_id = post_id; l.kernel = PTAMD_KERNEL_AUTO;
+  int rc = do_launch(ctx, &l, false);
+  if (rc == PTAMD_OK) ctx->frame_counter = seed;
+  return rc;
+}
+
+int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch) { return do_launch(ctx, launch, false); }
+
+int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_trace_stats* out)
+{
+  if (!ctx || !out) { set_error("ptamd_raytrace_stats: null argument"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = launch ? static_cast<hipStream_t>(launch->stream) : nullptr;
+  PT_HIP(hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), st));
+  int rc = do_launch(ctx, launch, true);
+  if (rc != PTAMD_OK) return rc;
+  PT_HIP(hipStreamSynchronize(st));
+  unsigned long long h[8];
+  PT_HIP(hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
+  out->mesh_hits = h[3]; out->nmap_hits = h[4]; out->samples = h[5];
+  return PTAMD_OK;
+}
+
+int ptamd_scene_info_get(ptamd_context* ctx, uint32_t scene_id, ptamd_scene_info* out)
+{
+  if (!ctx || !out || scene_id >= ctx->scenes.size()) { set_error("ptamd_scene_info_get: bad argument"); return PTAMD_ERR_ARG; }
+  *out = ctx->scenes[scene_id].info;
+  return PTAMD_OK;
+}
+
+int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, const float* rays_host, uint32_t n,
+                     int32_t* out_host)
+{
+  if (!ctx || scene_id >= ctx->scenes.size() || (n && (!rays_host || !out_host)) || kernel > PTAMD_KERNEL_BVH) {
+    set_error("ptamd_trace_rays: bad argument");
+    return PTAMD_ERR_ARG;
+  }
+  if (n == 0) return PTAMD_OK;
+  PT_HIP(hipSetDevice(ctx->device));
+  const DeviceScene& s = ctx->scenes[scene_id];
+  KParams p;
+  std::memset(&p, 0, sizeof p);
+  p.nodes = s.nodes; p.tris_bvh = s.tris_bvh; p.tris_brute = s.tris_brute; p.lights = s.lights;
+  p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes;
+  float* d_rays = nullptr;
+  int4* d_out = nullptr;
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 16);
+  if (e != hipSuccess) { hipFree(d_rays); return hip_fail("hipMalloc", e); }
+  int rc = PTAMD_OK;
+  if ((e = hipMemcpy(d_rays, rays_host, (size_t)n * 24, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = launch_trace_rays(p, kernel == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2, d_rays, n, d_out, nullptr)) != hipSuccess ||
+      (e = hipDeviceSynchronize()) != hipSuccess ||
+      (e = hipMemcpy(out_host, d_out, (size_t)n * 16, hipMemcpyDeviceToHost)) != hipSuccess)
+    rc = hip_fail("ptamd_trace_rays", e);
+  hipFree(d_rays);
+  hipFree(d_out);
+  return rc;
+}
+
+int ptamd_device_alloc(ptamd_context* ctx, size_t bytes, void** out)
+{
+  if (!ctx || !out) { set_error("ptamd_device_alloc: null argument"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  PT_HIP(hipMalloc(out, bytes ? bytes : 16));
+  return PTAMD_OK;
+}
+
+int ptamd_device_free(ptamd_context* ctx, void* p)
+{
+  if (!ctx) { set_error("ptamd_device_free: null context"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  PT_HIP(hipFree(p));
+  return PTAMD_OK;
+}
+
+int ptamd_device_memset(ptamd_context* ctx, void* p, int value, size_t bytes, void* stream)
+{
+  if (!ctx || !p) { set_error("ptamd_device_memset: null argument"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  PT_HIP(hipMemsetAsync(p, value, bytes, static_cast<hipStream_t>(stream)));
+  return PTAMD_OK;
+}
+
+int ptamd_device_to_host(ptamd_context* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream)
+{
+  if (!ctx || !dst_host || !src_dev) { set_error("ptamd_device_to_host: null argument"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  PT_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+  PT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return PTAMD_OK;
+}
+
+int ptamd_stream_synchronize(ptamd_context* ctx, void* stream)
+{
+  if (!ctx) { set_error("ptamd_stream_synchronize: null context"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  PT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return PTAMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,382 @@
+// bvh_builder.cpp — host SAH BVH builder + the host mirror of the device traversal.
+//
+// The reference has NO acceleration structure: its intersect() is a double loop over
+// every face (cuda_opengl/include/shaders/intersection.cuh:179-196).  The BVH is a
+// build-side accelerator whose contract is: for every ray, return exactly the record the
+// brute-force loop returns, i.e. the lexicographic minimum of (t, global face index) over
+// the faces whose Moller-Trumbore test passes with t > 0 (first-wins strict `<` in storage
+// order == that minimum).  Culling must therefore be conservative; see DESIGN.md
+// "Conservative boxes" for the margin argument and the measured miss rate.
+//
+// Layout (documented in ptamd_internal.h): 64-byte nodes with per-octant miss links so a
+// ray walks the tree front-to-back without a stack; triangles re-ordered leaf-major as
+// 48-byte {v0, e1, e2, global index} records.
+#include "ptamd_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace ptamd {
+
+namespace {
+
+struct Box {
+  float lo[3], hi[3];
+  void reset()
+  {
+    for (int a = 0; a < 3; ++a) { lo[a] = std::numeric_limits<float>::max(); hi[a] = -std::numeric_limits<float>::max(); }
+  }
+  void grow(const Box& b)
+  {
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
+  }
+  float half_area() const
+  {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0.f || dy < 0.f || dz < 0.f) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct Prim { Box box; float c[3]; uint32_t face; };
+
+struct BuildNode {
+  Box box;
+  int left = -1, right = -1; // build-node indices; leaf when left < 0
+  uint32_t first = 0, count = 0;
+  int axis = 0;
+};
+
+constexpr float kTravCost = 1.0f;
+constexpr float kIsectCost = 1.6f;
+constexpr int kBins = 32;
+
+struct Builder {
+  std::vector<Prim> prims;
+  std::vector<BuildNode> nodes;
+  uint32_t max_leaf = 4;
+  uint32_t depth = 0;
+
+  int build(uint32_t first, uint32_t count, uint32_t level)
+  {
+    depth = std::max(depth, level + 1);
+    int id = (int)nodes.size();
+    nodes.emplace_back();
+    Box box, cbox;
+    box.reset(); cbox.reset();
+    for (uint32_t i = first; i < first + count; ++i) {
+      box.grow(prims[i].box);
+      for (int a = 0; a < 3; ++a) {
+        cbox.lo[a] = std::min(cbox.lo[a], prims[i].c[a]);
+        cbox.hi[a] = std::max(cbox.hi[a], prims[i].c[a]);
+      }
+    }
+    nodes[id].box = box;
+    nodes[id].first = first;
+    nodes[id].count = count;
+    if (count == 1) return id;
+
+    // best split
+    float best_cost = std::numeric_limits<float>::max();
+    int best_axis = -1;
+    uint32_t best_mid = 0;   // sweep: split position in sorted order
+    float best_plane = 0.f;  // binned: centroid threshold
+    bool best_binned = false;
+    const float inv_area = 1.0f / std::max(box.half_area(), 1e-30f);
+
+    if (count <= 2048) {
+      std::vector<float> right_area(count);
+      for (int a = 0; a < 3; ++a) {
+        if (!(cbox.hi[a] > cbox.lo[a])) continue;
+        std::sort(prims.begin() + first, prims.begin() + first + count,
+                  [a](const Prim& x, const Prim& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.face < y.face); });
+        Box acc;
+        acc.reset();
+        for (uint32_t i = count; i-- > 1;) {
+          acc.grow(prims[first + i].box);
+          right_area[i] = acc.half_area();
+        }
+        acc.reset();
+        for (uint32_t i = 1; i < count; ++i) {
+          acc.grow(prims[first + i - 1].box);
+          float cost = kTravCost + kIsectCost * inv_area * (acc.half_area() * (float)i + right_area[i] * (float)(count - i));
+          if (cost < best_cost) { best_cost = cost; best_axis = a; best_mid = i; best_binned = false; }
+        }
+      }
+    } else {
+      for (int a = 0; a < 3; ++a) {
+        float ext = cbox.hi[a] - cbox.lo[a];
+        if (!(ext > 0.f)) continue;
+        Box bbox[kBins];
+        uint32_t bcnt[kBins];
+        for (int b = 0; b < kBins; ++b) { bbox[b].reset(); bcnt[b] = 0; }
+        float scale = (float)kBins / ext;
+        for (uint32_t i = first; i < first + count; ++i) {
+          int b = std::min(kBins - 1, std::max(0, (int)((prims[i].c[a] - cbox.lo[a]) * scale)));
+          bbox[b].grow(prims[i].box);
+          bcnt[b]++;
+        }
+        float rarea[kBins];
+        uint32_t rcnt[kBins];
+        Box acc;
+        acc.reset();
+        uint32_t n = 0;
+        for (int b = kBins - 1; b >= 1; --b) {
+          acc.grow(bbox[b]); n += bcnt[b];
+          rarea[b] = acc.half_area(); rcnt[b] = n;
+        }
+        acc.reset();
+        n = 0;
+        for (int b = 1; b < kBins; ++b) {
+          acc.grow(bbox[b - 1]); n += bcnt[b - 1];
+          if (n == 0 || rcnt[b] == 0) continue;
+          float cost = kTravCost + kIsectCost * inv_area * (acc.half_area() * (float)n + rarea[b] * (float)rcnt[b]);
+          if (cost < best_cost) {
+            best_cost = cost; best_axis = a; best_binned = true;
+            best_plane = cbox.lo[a] + (float)b / scale;
+          }
+        }
+      }
+    }
+
+    const float leaf_cost = kIsectCost * (float)count;
+    if (count <= max_leaf && (best_axis < 0 || leaf_cost <= best_cost)) return id; // leaf
+
+    uint32_t mid;
+    if (best_axis < 0) {
+      // all centroids coincide: split by face index halves
+      std::sort(prims.begin() + first, prims.begin() + first + count,
+                [](const Prim& x, const Prim& y) { return x.face < y.face; });
+      mid = count / 2;
+      best_axis = 0;
+    } else if (best_binned) {
+      const int a = best_axis;
+      const float plane = best_plane;
+      auto it = std::partition(prims.begin() + first, prims.begin() + first + count,
+                               [a, plane](const Prim& p) { return p.c[a] < plane; });
+      mid = (uint32_t)(it - (prims.begin() + first));
+      if (mid == 0 || mid == count) {
+        std::sort(prims.begin() + first, prims.begin() + first + count,
+                  [a](const Prim& x, const Prim& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.face < y.face); });
+        mid = count / 2;
+      }
+    } else {
+      const int a = best_axis;
+      std::sort(prims.begin() + first, prims.begin() + first + count,
+                [a](const Prim& x, const Prim& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.face < y.face); });
+      mid = best_mid;
+    }
+    int l = build(first, mid, level + 1);
+    int r = build(first + mid, count - mid, level + 1);
+    nodes[id].left = l;
+    nodes[id].right = r;
+    nodes[id].axis = best_axis;
+    return id;
+  }
+};
+
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+} // namespace
+
+int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t max_leaf, Bvh& out)
+{
+  out = Bvh();
+  if (n_faces == 0) return PTAMD_OK;
+  if (n_faces >= (1u << 24)) { set_error("build_bvh: more than 2^24 faces"); return PTAMD_ERR_LIMIT; }
+  if (max_leaf < 1) max_leaf = 1;
+  if (max_leaf > 15) max_leaf = 15;
+  Builder b;
+  b.max_leaf = max_leaf;
+  b.prims.resize(n_faces);
+  for (uint32_t i = 0; i < n_faces; ++i) {
+    Prim& p = b.prims[i];
+    p.face = i;
+    p.box.reset();
+    for (int k = 0; k < 3; ++k) {
+      const float* v = &faces[i].vertices[k].x;
+      for (int a = 0; a < 3; ++a) {
+        // NaN vertices would poison every ancestor box: keep them out of the bounds (such a
+        // face can never pass Moller-Trumbore either way)
+        if (v[a] == v[a]) { p.box.lo[a] = std::min(p.box.lo[a], v[a]); p.box.hi[a] = std::max(p.box.hi[a], v[a]); }
+      }
+    }
+    for (int a = 0; a < 3; ++a) {
+      if (p.box.lo[a] > p.box.hi[a]) { p.box.lo[a] = 0.f; p.box.hi[a] = 0.f; }
+      p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
+    }
+  }
+  b.nodes.reserve(2 * n_faces);
+  b.build(0, n_faces, 0);
+
+  // ---- flatten: DFS pre-order, left child first
+  const uint32_t n_nodes = (uint32_t)b.nodes.size();
+  std::vector<uint32_t> order(n_nodes), pos(n_nodes);
+  {
+    std::vector<int> stack;
+    stack.push_back(0);
+    uint32_t k = 0;
+    while (!stack.empty()) {
+      int id = stack.back();
+      stack.pop_back();
+      pos[id] = k;
+      order[k++] = (uint32_t)id;
+      if (b.nodes[id].left >= 0) {
+        stack.push_back(b.nodes[id].right);
+        stack.push_back(b.nodes[id].left);
+      }
+    }
+  }
+  out.n_nodes = n_nodes;
+  out.depth = b.depth;
+  out.nodes.assign((size_t)n_nodes * 16, 0.0f);
+  out.tris.assign((size_t)n_faces * 12, 0.0f);
+
+  // per-octant miss links: top-down.  miss[o] of the root is END.
+  std::vector<uint32_t> miss((size_t)n_nodes * 8, 0xFFFFFFFFu);
+  for (uint32_t k = 0; k < n_nodes; ++k) {
+    const BuildNode& bn = b.nodes[order[k]];
+    if (bn.left < 0) continue;
+    const uint32_t l = pos[bn.left], r = pos[bn.right];
+    for (int o = 0; o < 8; ++o) {
+      const bool right_first = (o >> bn.axis) & 1; // direction negative along the split axis
+      const uint32_t first = right_first ? r : l, second = right_first ? l : r;
+      miss[(size_t)first * 8 + o] = second;
+      miss[(size_t)second * 8 + o] = miss[(size_t)k * 8 + o];
+    }
+  }
+
+  uint32_t tri_cursor = 0;
+  for (uint32_t k = 0; k < n_nodes; ++k) {
+    const BuildNode& bn = b.nodes[order[k]];
+    float* q = &out.nodes[(size_t)k * 16];
+    for (int a = 0; a < 3; ++a) {
+      float lo = bn.box.lo[a], hi = bn.box.hi[a];
+      q[a] = lo - (margin + std::fabs(lo) * 1e-6f);
+      q[4 + a] = hi + (margin + std::fabs(hi) * 1e-6f);
+    }
+    uint32_t info = 0, child = 0;
+    if (bn.left < 0) {
+      info = tri_cursor | (bn.count << 24);
+      out.n_leaves++;
+      out.max_leaf = std::max(out.max_leaf, bn.count);
+      // triangles of a leaf in ascending global face index
+      std::vector<uint32_t> ids;
+      for (uint32_t i = 0; i < bn.count; ++i) ids.push_back(b.prims[bn.first + i].face);
+      std::sort(ids.begin(), ids.end());
+      for (uint32_t fi : ids) {
+        const ptamd_face& f = faces[fi];
+        float* t = &out.tris[(size_t)tri_cursor * 12];
+        // e1/e2 are the reference's v0v1/v0v2 (intersection.cuh:106-107): same subtraction
+        t[0] = f.vertices[0].x; t[1] = f.vertices[0].y; t[2] = f.vertices[0].z;
+        t[3] = f.vertices[1].x - f.vertices[0].x;
+        t[4] = f.vertices[1].y - f.vertices[0].y;
+        t[5] = f.vertices[1].z - f.vertices[0].z;
+        t[6] = f.vertices[2].x - f.vertices[0].x;
+        t[7] = f.vertices[2].y - f.vertices[0].y;
+        t[8] = f.vertices[2].z - f.vertices[0].z;
+        t[9] = u2f(fi);
+        tri_cursor++;
+      }
+    } else {
+      child = pos[bn.right] | ((uint32_t)bn.axis << 30);
+    }
+    q[3] = u2f(info);
+    q[7] = u2f(child);
+    for (int o = 0; o < 8; ++o) q[8 + o] = u2f(miss[(size_t)k * 8 + o]);
+  }
+  return PTAMD_OK;
+}
+
+// Mirror of the device traversal (csrc/pt_kernels.hip: traverse_bvh); float ops in the same
+// order.  Only the final (kind, index, t) has to agree with brute force — the set of
+// visited nodes is an implementation detail.
+void bvh_trace_host(const Bvh& bvh, const ptamd_face* faces, const float dir[3], const float origin[3],
+                    HostHit& out, uint64_t* nodes_visited, uint64_t* tris_tested)
+{
+  (void)faces;
+  const float MAX_DIST = 100000.0f;
+  float best_t = MAX_DIST, best_u = 0.f, best_v = 0.f;
+  uint32_t best_idx = 0xFFFFFFFFu;
+  const int oct = (dir[0] < 0.f ? 1 : 0) | (dir[1] < 0.f ? 2 : 0) | (dir[2] < 0.f ? 4 : 0);
+  const float inv[3] = { 1.0f / dir[0], 1.0f / dir[1], 1.0f / dir[2] };
+  uint32_t node = bvh.n_nodes ? 0u : 0xFFFFFFFFu;
+  while (node != 0xFFFFFFFFu) {
+    const float* q = &bvh.nodes[(size_t)node * 16];
+    if (nodes_visited) ++*nodes_visited;
+    float tnear = -std::numeric_limits<float>::infinity(), tfar = std::numeric_limits<float>::infinity();
+    for (int a = 0; a < 3; ++a) {
+      float t0 = (q[a] - origin[a]) * inv[a];
+      float t1 = (q[4 + a] - origin[a]) * inv[a];
+      tnear = std::fmax(tnear, std::fmin(t0, t1));
+      tfar = std::fmin(tfar, std::fmax(t0, t1));
+    }
+    const bool hit = tnear <= tfar * 1.0000005f && tfar >= 0.0f && tnear <= best_t;
+    const uint32_t info = f2u(q[3]);
+    const uint32_t miss = f2u(q[8 + oct]);
+    if (!hit) { node = miss; continue; }
+    const uint32_t count = info >> 24;
+    if (count == 0) {
+      const uint32_t child = f2u(q[7]);
+      const uint32_t right = child & 0x3FFFFFFFu, axis = child >> 30;
+      node = ((oct >> axis) & 1) ? right : node + 1;
+      continue;
+    }
+    const uint32_t first = info & 0xFFFFFFu;
+    for (uint32_t k = 0; k < count; ++k) {
+      const float* t = &bvh.tris[(size_t)(first + k) * 12];
+      if (tris_tested) ++*tris_tested;
+      // intersection.cuh:102-135, same operation order
+      const float e1x = t[3], e1y = t[4], e1z = t[5], e2x = t[6], e2y = t[7], e2z = t[8];
+      const float px = dir[1] * e2z - dir[2] * e2y;
+      const float py = dir[2] * e2x - dir[0] * e2z;
+      const float pz = dir[0] * e2y - dir[1] * e2x;
+      const float det = e1x * px + e1y * py + e1z * pz;
+      if ((double)det < 0.0000001) continue;
+      const float inv_det = 1.0f / det;
+      const float tx = origin[0] - t[0], ty = origin[1] - t[1], tz = origin[2] - t[2];
+      const float u = (tx * px + ty * py + tz * pz) * inv_det;
+      if (u < 0 || u > 1) continue;
+      const float qx = ty * e1z - tz * e1y;
+      const float qy = tz * e1x - tx * e1z;
+      const float qz = tx * e1y - ty * e1x;
+      const float v = (dir[0] * qx + dir[1] * qy + dir[2] * qz) * inv_det;
+      if (v < 0 || u + v > 1) continue;
+      const float tt = (e2x * qx + e2y * qy + e2z * qz) * inv_det;
+      const uint32_t idx = f2u(t[9]);
+      if (tt > 0.0f && (tt < best_t || (tt == best_t && idx < best_idx && best_idx != 0xFFFFFFFFu))) {
+        best_t = tt; best_idx = idx; best_u = u; best_v = v;
+      }
+    }
+    node = miss;
+  }
+  out.t = best_t;
+  out.u = best_u;
+  out.v = best_v;
+  if (best_idx == 0xFFFFFFFFu) { out.kind = 0; out.index = -1; }
+  else { out.kind = 1; out.index = (int32_t)best_idx; }
+}
+
+} // namespace ptamd
+
+extern "C" int ptamd_host_bvh_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
+                                    int32_t* out, uint64_t* counters)
+{
+  if ((n_faces && !faces) || (n && (!rays || !out))) { ptamd::set_error("ptamd_host_bvh_trace: null argument"); return PTAMD_ERR_ARG; }
+  ptamd::Bvh bvh;
+  int rc = ptamd::build_bvh(faces, n_faces, 1e-3f, 4, bvh);
+  if (rc != PTAMD_OK) return rc;
+  for (uint32_t i = 0; i < n; ++i) {
+    ptamd::HostHit h;
+    ptamd::bvh_trace_host(bvh, faces, rays + (size_t)i * 6, rays + (size_t)i * 6 + 3, h,
+                          counters ? &counters[0] : nullptr, counters ? &counters[1] : nullptr);
+    out[i * 4 + 0] = h.kind;
+    out[i * 4 + 1] = h.index;
+    std::memcpy(&out[i * 4 + 2], &h.t, 4);
+    out[i * 4 + 3] = 0;
+  }
+  return PTAMD_OK;
+}

@@ -1,0 +1,59 @@
+// ptamd_internal.h — shared declarations of libptamd's translation units (not installed).
+#pragma once
+
+#include "ptamd.h"
+
+#include <string>
+#include <vector>
+
+namespace ptamd {
+
+void set_error(const std::string& msg);
+
+// Output of the host loader: the flattened arrays ptamd_scene_desc points into.
+struct HostScene {
+  std::vector<ptamd_face> faces;
+  std::vector<uint32_t> mesh_sizes;
+  std::vector<ptamd_material> materials;
+  std::vector<ptamd_light> lights;
+  std::vector<ptamd_texture_desc> textures;
+  std::vector<float> texels;
+  std::vector<std::string> unloaded_textures; // image files named by the MTL that were not decoded
+  ptamd_camera camera;
+  std::string cubemap;
+};
+
+int load_host_scene(const char* scene_path, uint32_t flags, HostScene*& out);
+
+// ---- BVH (bvh_builder.cpp) -----------------------------------------------------------
+//
+// Binary SAH BVH, laid out for a stackless, per-octant ORDERED threaded traversal:
+//   node record = 64 bytes = 4 x float4
+//     q0 = { lo.x, lo.y, lo.z, bits(first_tri | count << 24) }   (count == 0: interior)
+//     q1 = { hi.x, hi.y, hi.z, 0 }
+//     q2,q3 = links[8]: for ray octant o (bit a set <=> dir[a] < 0),
+//             links[o] = hit_link | miss_link << 16 (node indices, 0xFFFF = end)
+//   interior: hit_link = the child nearer along the split axis for that octant,
+//             miss_link = where to go when the box is missed / the subtree is done
+//   leaf:     hit_link == miss_link (after its triangles, continue at miss_link)
+// Triangles are re-ordered leaf-major; record = 48 bytes = 3 x float4
+//     t0 = { v0.x, v0.y, v0.z, e1.x }  t1 = { e1.y, e1.z, e2.x, e2.y }
+//     t2 = { e2.z, bits(global face index), 0, 0 }      with e1 = v1 - v0, e2 = v2 - v0
+struct Bvh {
+  std::vector<float> nodes;      // 16 floats per node
+  std::vector<float> tris;       // 12 floats per triangle, leaf-major
+  uint32_t n_nodes = 0, n_leaves = 0, max_leaf = 0, depth = 0;
+};
+
+constexpr uint32_t kBvhEnd = 0xFFFFu;
+constexpr uint32_t kBvhMaxNodes = 0xFFFEu;
+
+// margin: absolute inflation added to every box face (see DESIGN.md "Conservative boxes")
+int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t max_leaf, Bvh& out);
+
+// Host traversal with the same structure the kernel uses (tests + stats cross-check).
+struct HostHit { int32_t kind; int32_t index; float t; float u, v; };
+void bvh_trace_host(const Bvh& bvh, const ptamd_face* faces, const float dir[3], const float origin[3],
+                    HostHit& out, uint64_t* nodes_visited, uint64_t* tris_tested);
+
+} // namespace ptamd

@@ -1,0 +1,573 @@
+// scene_loader.cpp — host-side scene input for the megakernel: .scene / OBJ / MTL -> the
+// flattened arrays of ptamd_scene_desc.
+//
+// Behavioural contract (what the device path receives must be what the reference would
+// have uploaded on Linux):
+//   .scene grammar ........ cuda_opengl/src/scene/scene.cpp:32-170
+//   OBJ semantics ......... tinyobjloader 1.0.8 as the reference calls it
+//                           (scene.cpp:341, LoadObj(..., triangulate = true)): shapes split
+//                           on `o`/`g`, per-face material ids, fan triangulation, negative
+//                           indices, file order preserved
+//   Face flattening ....... scene.cpp:218-262 (AoS Face, per-face tangent)
+//   Materials/textures .... material_loader.cpp:164-401 (diffuse rgb + specular a packed
+//                           into one RGBA float texture, 1x1 fallbacks, global texture ids)
+// Image decoding is not available in this build (no stb in the image, none vendored yet):
+// every texture file is treated as "failed to load", which is exactly what happens to
+// indoor.mtl's backslash paths in the reference on Linux (material_loader.cpp:97-104).
+// This is written from scratch; nothing here is taken from tinyobjloader.
+#include "ptamd_internal.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace ptamd {
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846; // M_PI of <math.h> (scene.cpp:10-11,76,101)
+
+inline ptamd_float3 f3(float x, float y, float z) { return ptamd_float3{ x, y, z }; }
+inline ptamd_float3 sub3(ptamd_float3 a, ptamd_float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline ptamd_float3 cross3(ptamd_float3 a, ptamd_float3 b)
+{
+  return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline ptamd_float3 normalize3(ptamd_float3 v)
+{
+  float inv = 1.0f / std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+  return f3(v.x * inv, v.y * inv, v.z * inv);
+}
+
+bool at_end(std::stringstream& s) { return s.peek() == std::char_traits<char>::eof(); }
+
+// scene.cpp:44-59: three floats; fails when the stream ends before the third one starts
+bool read_vec3(ptamd_float3& out, std::stringstream& s)
+{
+  if (at_end(s)) return false;
+  s >> out.x;
+  if (at_end(s)) return false;
+  s >> out.y;
+  if (at_end(s)) return false;
+  s >> out.z;
+  return true;
+}
+
+float read_float_or(std::stringstream& s, float fallback) // scene.cpp:32-42
+{
+  if (at_end(s)) return fallback;
+  float v = 0.0f;
+  s >> v;
+  return v;
+}
+
+bool read_camera(ptamd_camera& cam, std::stringstream& s) // scene.cpp:61-84
+{
+  if (!read_vec3(cam.position, s)) return false;
+  if (!read_vec3(cam.dir, s)) return false;
+  cam.dir = normalize3(cam.dir);
+  if (at_end(s)) return false;
+  s >> cam.fov_x;
+  cam.fov_x = (float)(((double)cam.fov_x * kPi) / 180.0);
+  cam.focus_dist = read_float_or(s, 2.0f);
+  cam.aperture = read_float_or(s, 0.125f);
+  cam.speed = 1.4f;
+  return true;
+}
+
+// ---------------------------------------------------------------- OBJ / MTL
+
+struct MtlEntry {
+  std::string name;
+  float diffuse[3] = { 0.f, 0.f, 0.f };
+  float specular[3] = { 0.f, 0.f, 0.f };
+  float ior = 1.f;
+  std::string diffuse_tex, specular_tex, bump_tex, normal_tex;
+};
+
+const char* skip_ws(const char* p)
+{
+  while (*p == ' ' || *p == '\t') ++p;
+  return p;
+}
+bool is_space(char c) { return c == ' ' || c == '\t'; }
+bool is_eol(char c) { return c == '\0' || c == '\r' || c == '\n'; }
+
+// decimal text -> float through double, as a real_t=float tinyobj build does
+float parse_real(const char*& p, float fallback = 0.0f)
+{
+  p = skip_ws(p);
+  if (is_eol(*p)) return fallback;
+  char* end = nullptr;
+  double v = std::strtod(p, &end);
+  if (end == p) {
+    p += std::strcspn(p, " \t\r");
+    return fallback;
+  }
+  p = end;
+  return (float)v;
+}
+
+std::string rest_of_line(const char* p)
+{
+  std::string s(p);
+  while (!s.empty() && (s.back() == '\r' || s.back() == '\n')) s.pop_back();
+  return s;
+}
+
+// texture statement: options (-bm 1.0, -s u v w, ...) precede the file name
+std::string parse_texture_name(const char* p)
+{
+  std::string name;
+  while (!is_eol(*p)) {
+    p = skip_ws(p);
+    if (is_eol(*p)) break;
+    if (*p == '-') {
+      // option: skip its keyword and numeric/on-off arguments
+      const char* kw = p;
+      p += std::strcspn(p, " \t\r");
+      std::string key(kw, p);
+      int nargs = 1;
+      if (key == "-o" || key == "-s" || key == "-t") nargs = 3;
+      else if (key == "-mm") nargs = 2;
+      for (int i = 0; i < nargs; ++i) {
+        p = skip_ws(p);
+        if (is_eol(*p)) break;
+        // -o/-s/-t take up to 3 numbers; stop early on a non-number
+        if (nargs == 3 && i > 0) {
+          char* e = nullptr;
+          std::strtod(p, &e);
+          if (e == p) break;
+        }
+        p += std::strcspn(p, " \t\r");
+      }
+      continue;
+    }
+    size_t n = std::strcspn(p, " \t\r");
+    name.assign(p, n);
+    p += n;
+  }
+  return name;
+}
+
+bool starts(const char* p, const char* kw)
+{
+  size_t n = std::strlen(kw);
+  return std::strncmp(p, kw, n) == 0 && is_space(p[n]);
+}
+
+bool load_mtl(const std::string& path, std::vector<MtlEntry>& out, std::map<std::string, int>& index)
+{
+  std::ifstream f(path);
+  if (!f.is_open()) return false;
+  MtlEntry cur;
+  bool have = false;
+  auto flush = [&]() {
+    if (have && !cur.name.empty()) {
+      index.insert(std::make_pair(cur.name, (int)out.size()));
+      out.push_back(cur);
+    }
+  };
+  std::string line;
+  while (std::getline(f, line)) {
+    size_t last = line.find_last_not_of(" \t\r\n");
+    if (last == std::string::npos) continue;
+    line.erase(last + 1);
+    const char* p = skip_ws(line.c_str());
+    if (*p == '\0' || *p == '#') continue;
+    if (starts(p, "newmtl")) {
+      flush();
+      cur = MtlEntry();
+      cur.name = rest_of_line(p + 7);
+      have = true;
+    } else if (p[0] == 'K' && p[1] == 'd' && is_space(p[2])) {
+      p += 2;
+      cur.diffuse[0] = parse_real(p); cur.diffuse[1] = parse_real(p); cur.diffuse[2] = parse_real(p);
+    } else if (p[0] == 'K' && p[1] == 's' && is_space(p[2])) {
+      p += 2;
+      cur.specular[0] = parse_real(p); cur.specular[1] = parse_real(p); cur.specular[2] = parse_real(p);
+    } else if (p[0] == 'N' && p[1] == 'i' && is_space(p[2])) {
+      p += 2;
+      cur.ior = parse_real(p);
+    } else if (starts(p, "map_Kd")) {
+      cur.diffuse_tex = parse_texture_name(p + 7);
+    } else if (starts(p, "map_Ks")) {
+      cur.specular_tex = parse_texture_name(p + 7);
+    } else if (starts(p, "map_bump") || starts(p, "map_Bump")) {
+      cur.bump_tex = parse_texture_name(p + 9);
+    } else if (starts(p, "bump")) {
+      cur.bump_tex = parse_texture_name(p + 5);
+    } else if (starts(p, "norm")) {
+      cur.normal_tex = parse_texture_name(p + 5);
+    }
+  }
+  flush();
+  return true;
+}
+
+struct Corner { int v = -1, vt = -1, vn = -1; };
+
+bool fix_index(int idx, int n, int& out)
+{
+  if (idx > 0) { out = idx - 1; return true; }
+  if (idx == 0) return false;
+  out = n + idx;
+  return true;
+}
+
+// i, i/j, i//k, i/j/k
+bool parse_corner(const char*& p, int nv, int nvn, int nvt, Corner& c)
+{
+  if (!fix_index(std::atoi(p), nv, c.v)) return false;
+  p += std::strcspn(p, "/ \t\r");
+  if (*p != '/') return true;
+  ++p;
+  if (*p == '/') {
+    ++p;
+    if (!fix_index(std::atoi(p), nvn, c.vn)) return false;
+    p += std::strcspn(p, "/ \t\r");
+    return true;
+  }
+  if (!fix_index(std::atoi(p), nvt, c.vt)) return false;
+  p += std::strcspn(p, "/ \t\r");
+  if (*p != '/') return true;
+  ++p;
+  if (!fix_index(std::atoi(p), nvn, c.vn)) return false;
+  p += std::strcspn(p, "/ \t\r");
+  return true;
+}
+
+struct ObjData {
+  std::vector<float> v, vn, vt;
+  // one entry per shape (tinyobj shape_t), triangles already fanned
+  struct Tri { Corner c[3]; int material; };
+  std::vector<std::vector<Tri>> shapes;
+  std::vector<MtlEntry> materials;
+};
+
+bool load_obj(const std::string& path, const std::string& mtl_dir, ObjData& obj, std::string& err)
+{
+  std::ifstream f(path);
+  if (!f.is_open()) {
+    err = "cannot open OBJ '" + path + "'";
+    return false;
+  }
+  std::map<std::string, int> mtl_index;
+  std::vector<ObjData::Tri> shape;                   // triangles already exported to the open shape
+  std::vector<std::vector<Corner>> group;            // pending polygons (one material)
+  int material = -1;
+
+  auto export_group = [&]() -> bool {
+    if (group.empty()) return false;
+    for (const auto& poly : group) {
+      if (poly.size() < 3) continue;
+      for (size_t k = 2; k < poly.size(); ++k) {
+        ObjData::Tri t;
+        t.c[0] = poly[0]; t.c[1] = poly[k - 1]; t.c[2] = poly[k];
+        t.material = material;
+        shape.push_back(t);
+      }
+    }
+    return true;
+  };
+
+  std::string line;
+  while (std::getline(f, line)) {
+    while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+    if (line.empty()) continue;
+    const char* p = skip_ws(line.c_str());
+    if (*p == '\0' || *p == '#') continue;
+    if (p[0] == 'v' && is_space(p[1])) {
+      p += 2;
+      float x = parse_real(p), y = parse_real(p), z = parse_real(p);
+      obj.v.push_back(x); obj.v.push_back(y); obj.v.push_back(z);
+    } else if (p[0] == 'v' && p[1] == 'n' && is_space(p[2])) {
+      p += 3;
+      float x = parse_real(p), y = parse_real(p), z = parse_real(p);
+      obj.vn.push_back(x); obj.vn.push_back(y); obj.vn.push_back(z);
+    } else if (p[0] == 'v' && p[1] == 't' && is_space(p[2])) {
+      p += 3;
+      float x = parse_real(p), y = parse_real(p);
+      obj.vt.push_back(x); obj.vt.push_back(y);
+    } else if (p[0] == 'f' && is_space(p[1])) {
+      p = skip_ws(p + 2);
+      std::vector<Corner> poly;
+      while (!is_eol(*p)) {
+        Corner c;
+        if (!parse_corner(p, (int)(obj.v.size() / 3), (int)(obj.vn.size() / 3), (int)(obj.vt.size() / 2), c)) {
+          err = "bad face index in '" + path + "'";
+          return false;
+        }
+        poly.push_back(c);
+        p += std::strspn(p, " \t\r");
+      }
+      group.push_back(std::move(poly));
+    } else if (starts(p, "usemtl")) {
+      std::string name = rest_of_line(p + 7);
+      int id = -1;
+      auto it = mtl_index.find(name);
+      if (it != mtl_index.end()) id = it->second;
+      if (id != material) {
+        export_group();
+        group.clear();
+        material = id;
+      }
+    } else if (starts(p, "mtllib")) {
+      std::stringstream ss(rest_of_line(p + 7));
+      std::string fn;
+      while (std::getline(ss, fn, ' ')) {
+        if (fn.empty()) continue;
+        if (load_mtl(mtl_dir + fn, obj.materials, mtl_index)) break;
+      }
+    } else if (p[0] == 'g' && is_space(p[1])) {
+      export_group();
+      if (!shape.empty()) obj.shapes.push_back(shape);
+      shape.clear();
+      group.clear();
+    } else if (p[0] == 'o' && is_space(p[1])) {
+      bool any = export_group();
+      if (any) obj.shapes.push_back(shape);
+      shape.clear();
+      group.clear();
+    }
+  }
+  bool any = export_group();
+  if (any || !shape.empty()) obj.shapes.push_back(shape);
+  return true;
+}
+
+} // namespace
+
+// material_loader.cpp:164-197 with every image load failing (see file header): the
+// diffuse+specular texture is always the 1x1 RGBA fallback, the normal map is -1.
+static void build_materials(const ObjData& obj, HostScene& hs)
+{
+  for (const MtlEntry& m : obj.materials) {
+    ptamd_material mat{};
+    float default_spec = (float)(((double)(m.specular[0] + m.specular[1] + m.specular[2])) / 3.0);
+    // CASE 1 (no names) and the "load failed" arms of CASE 2/3 all push the same unit texture
+    ptamd_texture_desc td{};
+    td.w = 1; td.h = 1; td.nb_chan = 4;
+    td.offset = hs.texels.size();
+    hs.texels.push_back(m.diffuse[0]);
+    hs.texels.push_back(m.diffuse[1]);
+    hs.texels.push_back(m.diffuse[2]);
+    hs.texels.push_back(default_spec);
+    mat.diffuse_spec_map = (int32_t)hs.textures.size();
+    hs.textures.push_back(td);
+    // registerOrGet (material_loader.cpp:384-401): a failed load yields -1 and no id is consumed
+    mat.normal_map = -1;
+    mat.ior = m.ior;
+    hs.materials.push_back(mat);
+    const std::string& nm = !m.bump_tex.empty() ? m.bump_tex : m.normal_tex;
+    if (!m.diffuse_tex.empty()) hs.unloaded_textures.push_back(m.diffuse_tex);
+    if (!m.specular_tex.empty()) hs.unloaded_textures.push_back(m.specular_tex);
+    if (!nm.empty()) hs.unloaded_textures.push_back(nm);
+  }
+}
+
+// scene.cpp:218-262
+static bool build_faces(const ObjData& obj, HostScene& hs, std::string& err)
+{
+  const int nv = (int)(obj.v.size() / 3), nvn = (int)(obj.vn.size() / 3), nvt = (int)(obj.vt.size() / 2);
+  for (const auto& shape : obj.shapes) {
+    hs.mesh_sizes.push_back((uint32_t)shape.size());
+    for (const auto& t : shape) {
+      ptamd_face face{};
+      for (int k = 0; k < 3; ++k) {
+        const Corner& c = t.c[k];
+        if (c.v < 0 || c.v >= nv) { err = "vertex index out of range"; return false; }
+        face.vertices[k] = f3(obj.v[3 * c.v], obj.v[3 * c.v + 1], obj.v[3 * c.v + 2]);
+        // the reference indexes normals[-3]/texcoords[-2] when a corner has none (undefined
+        // behaviour, scene.cpp:241-247); defined here as zeros
+        if (c.vn >= 0 && c.vn < nvn)
+          face.normals[k] = f3(obj.vn[3 * c.vn], obj.vn[3 * c.vn + 1], obj.vn[3 * c.vn + 2]);
+        if (c.vt >= 0 && c.vt < nvt)
+          face.texcoords[k] = ptamd_float2{ obj.vt[2 * c.vt], obj.vt[2 * c.vt + 1] };
+      }
+      if (t.material < 0 || t.material >= (int)hs.materials.size()) {
+        // reference: materials.data[-1] (out of bounds).  Refuse instead of reading garbage.
+        err = "face without a valid material (usemtl missing or unknown)";
+        return false;
+      }
+      face.material_id = (uint32_t)t.material;
+      ptamd_float3 e1 = sub3(face.vertices[1], face.vertices[0]);
+      ptamd_float3 e2 = sub3(face.vertices[2], face.vertices[0]);
+      float du1 = face.texcoords[1].x - face.texcoords[0].x, dv1 = face.texcoords[1].y - face.texcoords[0].y;
+      float du2 = face.texcoords[2].x - face.texcoords[0].x, dv2 = face.texcoords[2].y - face.texcoords[0].y;
+      float f = 1.0f / (du1 * dv2 - du2 * dv1);
+      face.tangent.x = f * (dv2 * e1.x - dv1 * e2.x);
+      face.tangent.y = f * (dv2 * e1.y - dv1 * e2.y);
+      face.tangent.z = f * (dv2 * e1.z - dv1 * e2.z);
+      hs.faces.push_back(face);
+    }
+  }
+  return true;
+}
+
+int load_host_scene(const char* scene_path, uint32_t flags, HostScene*& out)
+{
+  (void)flags; // bit 0 only matters once image decoding exists
+  std::ifstream file(scene_path);
+  if (!file.is_open()) {
+    set_error(std::string("cannot open scene file '") + scene_path + "'");
+    return PTAMD_ERR_IO;
+  }
+  HostScene* hs = new HostScene();
+  // default camera (scene.cpp:98-102); position/focus/aperture are indeterminate in the
+  // reference when no camera line exists — defined here
+  ptamd_camera& cam = hs->camera;
+  std::memset(&cam, 0, sizeof cam);
+  cam.u = f3(1.0f, 0.0f, 0.0f);
+  cam.v = f3(0.0f, -1.0f, 0.0f);
+  cam.fov_x = (float)((90.0 * kPi) / 180.0);
+  cam.dir = cross3(cam.u, cam.v);
+  cam.focus_dist = 2.0f;
+  cam.aperture = 0.125f;
+  cam.speed = 1.4f;
+
+  std::string objfile, line, token;
+  while (std::getline(file, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    std::stringstream iss(line);
+    token.clear();
+    iss >> token;
+    if (token == "p_light") {
+      ptamd_light l{};
+      if (!read_vec3(l.vec, iss)) continue;
+      if (!read_vec3(l.color, iss)) continue;
+      if (at_end(iss)) continue;
+      iss >> l.emission;
+      if (at_end(iss)) continue;
+      iss >> l.radius;
+      hs->lights.push_back(l);
+    } else if (token == "scene") {
+      if (at_end(iss)) continue;
+      iss >> objfile;
+    } else if (token == "camera") {
+      ptamd_camera c = cam;
+      if (read_camera(c, iss)) cam = c;
+      else cam = c; // the reference parses in place: a partial parse leaves partial values
+    } else if (token == "cubemap") {
+      if (!at_end(iss)) iss >> hs->cubemap;
+    }
+  }
+
+  // scene.cpp:329-339
+  std::string path(scene_path), base_dir, mtl_dir, full_obj;
+  std::string::size_type pos = path.find_last_of('/');
+  if (pos != std::string::npos) {
+    base_dir = path.substr(0, pos) + "/";
+    mtl_dir = base_dir;
+    full_obj = base_dir + objfile;
+  }
+  pos = objfile.find_last_of('/');
+  if (pos != std::string::npos) mtl_dir = base_dir + "/" + objfile.substr(0, pos) + "/";
+
+  ObjData obj;
+  std::string err;
+  if (!load_obj(full_obj, mtl_dir, obj, err)) {
+    set_error("scene '" + path + "': " + err);
+    delete hs;
+    return PTAMD_ERR_IO;
+  }
+  build_materials(obj, *hs);
+  if (!build_faces(obj, *hs, err)) {
+    set_error("scene '" + path + "': " + err);
+    delete hs;
+    return PTAMD_ERR_IO;
+  }
+  out = hs;
+  return PTAMD_OK;
+}
+
+} // namespace ptamd
+
+// ------------------------------------------------------------------------ C-ABI
+
+extern "C" {
+
+int ptamd_host_scene_load(const char* scene_path, uint32_t flags, ptamd_host_scene** out)
+{
+  if (!scene_path || !out) { ptamd::set_error("ptamd_host_scene_load: null argument"); return PTAMD_ERR_ARG; }
+  ptamd::HostScene* hs = nullptr;
+  int rc = ptamd::load_host_scene(scene_path, flags, hs);
+  if (rc != PTAMD_OK) return rc;
+  *out = reinterpret_cast<ptamd_host_scene*>(hs);
+  return PTAMD_OK;
+}
+
+void ptamd_host_scene_free(ptamd_host_scene* s) { delete reinterpret_cast<ptamd::HostScene*>(s); }
+
+int ptamd_host_scene_desc(const ptamd_host_scene* s, ptamd_scene_desc* out)
+{
+  if (!s || !out) { ptamd::set_error("ptamd_host_scene_desc: null argument"); return PTAMD_ERR_ARG; }
+  const ptamd::HostScene* hs = reinterpret_cast<const ptamd::HostScene*>(s);
+  std::memset(out, 0, sizeof *out);
+  out->faces = hs->faces.data();           out->n_faces = (uint32_t)hs->faces.size();
+  out->mesh_sizes = hs->mesh_sizes.data(); out->n_meshes = (uint32_t)hs->mesh_sizes.size();
+  out->materials = hs->materials.data();   out->n_materials = (uint32_t)hs->materials.size();
+  out->lights = hs->lights.data();         out->n_lights = (uint32_t)hs->lights.size();
+  out->textures = hs->textures.data();     out->n_textures = (uint32_t)hs->textures.size();
+  out->texels = hs->texels.data();         out->n_texel_floats = hs->texels.size();
+  return PTAMD_OK;
+}
+
+int ptamd_host_scene_camera(const ptamd_host_scene* s, ptamd_camera* out)
+{
+  if (!s || !out) { ptamd::set_error("ptamd_host_scene_camera: null argument"); return PTAMD_ERR_ARG; }
+  *out = reinterpret_cast<const ptamd::HostScene*>(s)->camera;
+  return PTAMD_OK;
+}
+
+const char* ptamd_host_scene_cubemap(const ptamd_host_scene* s)
+{
+  if (!s) return "";
+  return reinterpret_cast<const ptamd::HostScene*>(s)->cubemap.c_str();
+}
+
+// gpu_processor.cpp:37-57
+int ptamd_cubemap_from_color(uint32_t rgb, float out[24])
+{
+  if (!out) { ptamd::set_error("ptamd_cubemap_from_color: null argument"); return PTAMD_ERR_ARG; }
+  float r = (float)((rgb >> 16) & 0xFF) / 255.0f;
+  float g = (float)((rgb >> 8) & 0xFF) / 255.0f;
+  float b = (float)(rgb & 0xFF) / 255.0f;
+  for (int f = 0; f < 6; ++f) {
+    out[f * 4 + 0] = r; out[f * 4 + 1] = g; out[f * 4 + 2] = b; out[f * 4 + 3] = 0.0f;
+  }
+  return PTAMD_OK;
+}
+
+// gpu_processor.cpp:101-127 + texture_utils.cpp:5-52: a 4x3 cube cross; faces cut as
+// +x=(col2,row1) -x=(col0,row1) +y=(col1,row0) -y=(col1,row2) +z=(col1,row1) -z=(col3,row1)
+int ptamd_cubemap_from_cross(const float* cross, uint32_t width, uint32_t height, uint32_t nb_chan,
+                             float* out, uint32_t* out_size)
+{
+  if (!cross || !out || !out_size || nb_chan < 3) {
+    ptamd::set_error("ptamd_cubemap_from_cross: bad argument");
+    return PTAMD_ERR_ARG;
+  }
+  uint32_t size = width / 4;
+  if (size == 0 || size != height / 3) { ptamd::set_error("cubemap: width and height are not the same"); return PTAMD_ERR_ARG; }
+  if (size & (size - 1)) { ptamd::set_error("cubemap: size should be a power of 2"); return PTAMD_ERR_ARG; }
+  static const uint32_t col[6] = { 2, 0, 1, 1, 1, 3 };
+  static const uint32_t row[6] = { 1, 1, 0, 2, 1, 1 };
+  float* dst = out;
+  for (int f = 0; f < 6; ++f)
+    for (uint32_t y = 0; y < size; ++y)
+      for (uint32_t x = 0; x < size; ++x) {
+        const float* src = cross + ((size_t)(y + row[f] * size) * width + (x + col[f] * size)) * nb_chan;
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = 0.0f;
+        dst += 4;
+      }
+  *out_size = size;
+  return PTAMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's render boundary.
+
+Reference interface (cuda_opengl/include/shaders/raytrace.h:9-17):
+
+    cudaError_t raytrace(cudaArray_const_t array, const scene::Scenes& scenes,
+                         unsigned scene_id, const std::vector<scene::Cubemap>& cubemaps,
+                         int cubemap_id, const scene::Camera* cam, unsigned width,
+                         unsigned height, cudaStream_t stream, float3* temporal_framebuffer,
+                         bool moved, unsigned post_id);
+    void setupFunctionTables();
+
+`Context.raytrace` keeps the same argument meaning (the scene/cubemap tables live in the
+context, as GPUProcessor owns them in the reference: gpu_processor.cpp:271-331), launches
+asynchronously on the given stream and borrows the caller's device buffers.  torch is used
+only to own device memory and streams; every pixel is produced by libptamd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import native as N
+from .scene import HostScene
+
+POST_NONE, POST_GRAYSCALE, POST_SEPIA, POST_INVERT = 0, 1, 2, 3
+REFERENCE_BOUNCES = 3  # static_samples = 1 -> max_bounces = 3 (raytrace.cu:243,66)
+
+
+def _ptr(buf) -> int:
+    """Device address of a torch tensor / raw int pointer."""
+    if isinstance(buf, int):
+        return buf
+    if hasattr(buf, "data_ptr"):
+        if not buf.is_cuda:
+            raise ValueError("output buffers must live in device memory (no CPU path exists)")
+        if not buf.is_contiguous():
+            raise ValueError("output buffers must be contiguous")
+        return buf.data_ptr()
+    raise TypeError(f"unsupported buffer type {type(buf)!r}")
+
+
+def _stream_handle(stream) -> int:
+    if stream is None:
+        return 0
+    if isinstance(stream, int):
+        return stream
+    return int(stream.cuda_stream)  # torch.cuda.Stream
+
+
+class Context:
+    """One device context = the device-side state GPUProcessor holds for raytrace()."""
+
+    def __init__(self, device: int = 0):
+        self._lib = N.load()
+        h = C.c_void_p()
+        N.check(self._lib.ptamd_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ptamd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- uploads (scene.cpp:370-391, gpu_processor.cpp:68-238)
+    def upload_scene(self, scene: HostScene) -> int:
+        d = scene.desc()
+        sid = C.c_uint32()
+        N.check(self._lib.ptamd_upload_scene(self._h, C.byref(d), C.byref(sid)))
+        return sid.value
+
+    def upload_cubemap(self, faces: np.ndarray) -> int:
+        faces = np.ascontiguousarray(faces, dtype=np.float32)
+        if faces.ndim != 4 or faces.shape[0] != 6 or faces.shape[1] != faces.shape[2] or faces.shape[3] != 4:
+            raise ValueError("cubemap must be float32[6, size, size, 4]")
+        cid = C.c_uint32()
+        N.check(self._lib.ptamd_upload_cubemap(self._h, faces.ctypes.data_as(C.POINTER(C.c_float)),
+                                               faces.shape[1], C.byref(cid)))
+        return cid.value
+
+    def setup_function_tables(self) -> None:
+        """setupFunctionTables() (raytrace.cu:360-375)."""
+        N.check(self._lib.ptamd_setup_function_tables(self._h))
+
+    def scene_info(self, scene_id: int) -> dict:
+        info = N.SceneInfo()
+        N.check(self._lib.ptamd_scene_info_get(self._h, scene_id, C.byref(info)))
+        return {n: getattr(info, n) for n, _ in N.SceneInfo._fields_}
+
+    # ---- the hot path
+    def raytrace(self, array, scene_id: int, cubemap_id: int, cam: N.Camera, width: int, height: int,
+                 stream, temporal_framebuffer, moved: bool, post_id: int) -> None:
+        """One reference raytrace() call: 1 spp, context-held frame counter, 3 bounces."""
+        N.check(self._lib.ptamd_raytrace(self._h, _ptr(array), scene_id, cubemap_id, C.byref(cam), width, height,
+                                         _stream_handle(stream), _ptr(temporal_framebuffer),
+                                         1 if moved else 0, post_id))
+
+    def reset_frame_counter(self) -> None:
+        N.check(self._lib.ptamd_reset_frame_counter(self._h))
+
+    def make_launch(self, array, temporal_framebuffer, scene_id: int, cubemap_id: int, cam: N.Camera,
+                    width: int, height: int, frame_nb: int, bounces: int = REFERENCE_BOUNCES,
+                    moved: bool = False, post_id: int = POST_NONE, stream=None,
+                    rows: Optional[tuple] = None, kernel: int = N.KERNEL_AUTO,
+                    band_local_buffers: bool = False) -> N.Launch:
+        l = N.Launch()
+        l.surface_rgba8 = _ptr(array)
+        l.temporal_framebuffer = _ptr(temporal_framebuffer)
+        l.stream = _stream_handle(stream)
+        l.camera = cam
+        l.scene_id, l.cubemap_id = scene_id, cubemap_id
+        l.width, l.height = width, height
+        l.row_begin, l.row_end = rows if rows is not None else (0, height)
+        l.frame_nb, l.bounces = frame_nb, bounces
+        l.moved, l.post_id, l.kernel = (1 if moved else 0), post_id, kernel
+        l.band_local_buffers = 1 if band_local_buffers else 0
+        return l
+
+    def raytrace_ex(self, launch: N.Launch) -> None:
+        N.check(self._lib.ptamd_raytrace_ex(self._h, C.byref(launch)))
+
+    def raytrace_stats(self, launch: N.Launch) -> dict:
+        st = N.TraceStats()
+        N.check(self._lib.ptamd_raytrace_stats(self._h, C.byref(launch), C.byref(st)))
+        return {n: getattr(st, n) for n, _ in N.TraceStats._fields_}
+
+    def trace_rays(self, scene_id: int, rays: np.ndarray, kernel: int = N.KERNEL_BVH) -> np.ndarray:
+        """rays float32[n,6] = dir.xyz, origin.xyz -> int32[n,4] = kind, index, t bits, 0."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        out = np.zeros((len(rays), 4), dtype=np.int32)
+        N.check(self._lib.ptamd_trace_rays(self._h, scene_id, kernel, rays.ctypes.data_as(C.POINTER(C.c_float)),
+                                           len(rays), out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def synchronize(self, stream=None) -> None:
+        N.check(self._lib.ptamd_stream_synchronize(self._h, _stream_handle(stream)))
+
+
+def host_bvh_trace(scene: HostScene, rays: np.ndarray):
+    """Host mirror of the device BVH walk (test hook, no GPU): returns (int32[n,4], nodes, tris)."""
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    out = np.zeros((len(rays), 4), dtype=np.int32)
+    counters = (C.c_uint64 * 2)(0, 0)
+    N.check(N.load().ptamd_host_bvh_trace(scene.faces.ctypes.data_as(C.POINTER(N.Face)), len(scene.faces),
+                                          rays.ctypes.data_as(C.POINTER(C.c_float)), len(rays),
+                                          out.ctypes.data_as(C.POINTER(C.c_int32)), counters))
+    return out, counters[0], counters[1]
+
+
+def wang_hash(a: int) -> int:
+    return N.load().ptamd_wang_hash(a & 0xFFFFFFFF)
+
+
+class FrameRenderer:
+    """N-spp frame driver: N consecutive static launches with frame seeds 1..N accumulating
+    into the temporal framebuffer — how the reference converges an image (raytrace.cu:255-258,
+    296-300).  Buffers are torch tensors on the context's device."""
+
+    def __init__(self, ctx: Context, scene_id: int, cubemap_id: int, cam: N.Camera, width: int, height: int,
+                 rows: Optional[tuple] = None, band_local: bool = False):
+        import torch
+        self.ctx, self.scene_id, self.cubemap_id, self.cam = ctx, scene_id, cubemap_id, cam
+        self.width, self.height = width, height
+        self.rows = rows if rows is not None else (0, height)
+        self.band_local = band_local
+        n_rows = (self.rows[1] - self.rows[0]) if band_local else height
+        dev = torch.device("cuda", ctx.device)
+        self.surface = torch.zeros((n_rows, width, 4), dtype=torch.uint8, device=dev)
+        self.accum = torch.zeros((n_rows, width, 3), dtype=torch.float32, device=dev)
+
+    def reset(self) -> None:
+        self.accum.zero_()
+        self.surface.zero_()
+
+    def render(self, spp: int, bounces: int = REFERENCE_BOUNCES, post_id: int = POST_NONE,
+               kernel: int = N.KERNEL_AUTO, stream=None, first_frame: int = 1) -> None:
+        for k in range(first_frame, first_frame + spp):
+            l = self.ctx.make_launch(self.surface, self.accum, self.scene_id, self.cubemap_id, self.cam,
+                                     self.width, self.height, frame_nb=k, bounces=bounces, post_id=post_id,
+                                     stream=stream, rows=self.rows, kernel=kernel,
+                                     band_local_buffers=self.band_local)
+            self.ctx.raytrace_ex(l)

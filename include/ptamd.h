@@ -1,0 +1,237 @@
+/*
+ * ptamd.h — C-ABI of the MI355X-native path-tracing megakernel (libptamd.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of DavidPeicho/cuda-pathtracer:
+ *     cudaError_t raytrace(...)   and   void setupFunctionTables()
+ *     (reference: cuda_opengl/include/shaders/raytrace.h:9-17, implemented in
+ *      cuda_opengl/src/shaders/raytrace.cu:287-375; called from
+ *      cuda_opengl/src/gpu_processor.cpp:375-377 and cuda_opengl/src/main.cpp:170)
+ * plus the device-side data the reference hands to it (scene upload:
+ * cuda_opengl/src/scene/scene.cpp:202-283,370-391; textures/cubemaps:
+ * cuda_opengl/src/gpu_processor.cpp:68-238).
+ *
+ * Conventions: plain C, plain pointers and sizes, no C++/STL/torch types.  Every
+ * function returns 0 (PTAMD_OK) on success and a non-zero ptamd_status otherwise; it
+ * never throws, never calls exit().  The message of the last failure on the calling
+ * thread is returned by ptamd_get_last_error().  Calls on one context must be
+ * serialised by the caller (the reference is single-threaded: gpu_processor.cpp:254).
+ *
+ * There is NO CPU fallback behind this API: compute entry points fail with
+ * PTAMD_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef PTAMD_H
+#define PTAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  PTAMD_OK = 0,
+  PTAMD_ERR_ARG = 1,     /* null pointer / out-of-range id / bad size */
+  PTAMD_ERR_HIP = 2,     /* a HIP runtime call failed (message has hipGetErrorString) */
+  PTAMD_ERR_IO = 3,      /* loader: file missing / unparsable */
+  PTAMD_ERR_LIMIT = 4    /* scene exceeds a documented capacity */
+} ptamd_status;
+
+/* ---- POD layouts: byte-compatible with cuda_opengl/include/scene/scene_data.h -------- */
+
+typedef struct { float x, y, z; } ptamd_float3;
+typedef struct { float x, y; } ptamd_float2;
+
+/* scene::Face, scene_data.h:46-53 — 112 bytes */
+typedef struct {
+  ptamd_float3 vertices[3];
+  ptamd_float3 normals[3];
+  ptamd_float2 texcoords[3];
+  ptamd_float3 tangent;
+  uint32_t material_id;
+} ptamd_face;
+
+/* scene::Material, scene_data.h:95-100 — 16 bytes (12 + alignment pad) */
+typedef struct {
+  int32_t diffuse_spec_map;   /* id into the texture table (RGBA float: rgb = albedo, a = specular) */
+  int32_t normal_map;         /* id into the texture table (RGB float) or -1 */
+  float ior;
+  int32_t _pad;
+} ptamd_material;
+
+/* scene::LightProp, scene_data.h:109-115 — 32 bytes */
+typedef struct {
+  ptamd_float3 color;
+  ptamd_float3 vec;
+  float emission;
+  float radius;
+} ptamd_light;
+
+/* scene::Camera, scene_data.h:123-133 — 64 bytes.  u and v are ignored by the kernel
+ * exactly as in the reference (generateRay recomputes them, intersection.cuh:84-87). */
+typedef struct {
+  ptamd_float3 position;
+  ptamd_float3 dir;
+  ptamd_float3 u;
+  ptamd_float3 v;
+  float fov_x;
+  float speed;
+  float aperture;
+  float focus_dist;
+} ptamd_camera;
+
+/* scene::Texture, scene_data.h:31-37, with the data pointer replaced by an offset (in
+ * floats) into one texel blob */
+typedef struct {
+  int32_t w, h, nb_chan;
+  uint32_t _pad;
+  uint64_t offset;
+} ptamd_texture_desc;
+
+/* Flattened scene::SceneData + the global texture table (scene_data.h:71-87).
+ * Faces are mesh-major in storage order: mesh m owns faces
+ * [sum(mesh_sizes[0..m)), +mesh_sizes[m]).  The global face index in that order is the
+ * tie-break key of the nearest-hit search (intersection.cuh:179-196: first wins). */
+typedef struct {
+  const ptamd_face* faces;            uint32_t n_faces;
+  const uint32_t* mesh_sizes;         uint32_t n_meshes;
+  const ptamd_material* materials;    uint32_t n_materials;
+  const ptamd_light* lights;          uint32_t n_lights;
+  const ptamd_texture_desc* textures; uint32_t n_textures;
+  const float* texels;                uint64_t n_texel_floats;
+} ptamd_scene_desc;
+
+/* ---- errors ------------------------------------------------------------------------ */
+
+const char* ptamd_get_last_error(void);
+const char* ptamd_version(void);
+
+/* ---- host-side scene loader (replaces scene::Scene::upload's parsing half,
+ *      scene.cpp:86-170,202-262,304-358 and material_loader.cpp:153-401) --------------- */
+
+typedef struct ptamd_host_scene ptamd_host_scene;
+
+/* Parses a .scene file and the OBJ/MTL it names.  flags: bit 0 = normalise '\\' to '/'
+ * in MTL texture paths (default 0 = reference-on-Linux behaviour: such textures fail to
+ * load and degrade to 1x1 constants, material_loader.cpp:97-104). */
+int  ptamd_host_scene_load(const char* scene_path, uint32_t flags, ptamd_host_scene** out);
+void ptamd_host_scene_free(ptamd_host_scene* s);
+/* Borrowed views into the loaded scene, valid until ptamd_host_scene_free. */
+int  ptamd_host_scene_desc(const ptamd_host_scene* s, ptamd_scene_desc* out);
+int  ptamd_host_scene_camera(const ptamd_host_scene* s, ptamd_camera* out);
+/* "" when the .scene has no cubemap line; "0xRRGGBB" constant syntax is returned as is. */
+const char* ptamd_host_scene_cubemap(const ptamd_host_scene* s);
+
+/* Cubemap helpers (gpu_processor.cpp:37-57,68-132; texture_utils.cpp:5-52):
+ * constant-colour 1x1x6 cubemap from 0xRRGGBB, and cube-cross -> 6 faces unpack
+ * (+x,-x,+y,-y,+z,-z, float4 per texel, w = 0).  out must hold 6*size*size*4 floats. */
+int ptamd_cubemap_from_color(uint32_t rgb, float out[24]);
+int ptamd_cubemap_from_cross(const float* cross, uint32_t width, uint32_t height,
+                             uint32_t nb_chan, float* out, uint32_t* out_size);
+
+/* ---- device context ------------------------------------------------------------------ */
+
+typedef struct ptamd_context ptamd_context;
+
+int  ptamd_create(int32_t device_ordinal, ptamd_context** out);
+void ptamd_destroy(ptamd_context* ctx);
+
+/* Deep-copies a flattened scene to the device and builds the traversal structures
+ * (replaces scene.cpp:177-283,370-391 + gpu_processor.cpp:178-238).  Host arrays are
+ * copied; the caller keeps ownership. */
+int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* scene, uint32_t* out_scene_id);
+/* faces: 6*size*size float4 in +x,-x,+y,-y,+z,-z order (gpu_processor.cpp:134-153). */
+int ptamd_upload_cubemap(ptamd_context* ctx, const float* faces, uint32_t size, uint32_t* out_cubemap_id);
+
+/* setupFunctionTables() (raytrace.cu:360-375).  The reference copies four device
+ * function pointers to the host; here post-process dispatch is a switch inside the
+ * kernel, so this only validates that the device code object is loadable. */
+int ptamd_setup_function_tables(ptamd_context* ctx);
+
+/* ---- the hot path ---------------------------------------------------------------------
+ * ptamd_raytrace == one reference raytrace() call (raytrace.cu:287-325): 1 sample per
+ * pixel, frame counter kept in the context (the reference's function-static `seed`,
+ * raytrace.cu:296-300): moved -> counter = 0; ++counter; hash_seed = WangHash(counter).
+ * Bounce count is the reference's hard-coded 3 (static_samples = 1, raytrace.cu:243).
+ *   surface_rgba8 : device pointer, width*height*4 bytes, row 0 = top of the picture
+ *                   (replaces the cudaArray of the GL renderbuffer, raytrace.cu:270)
+ *   temporal_framebuffer : device pointer, float3[width*height], reference row-flipped
+ *                   index (raytrace.cu:252); borrowed, like the reference's
+ *   stream        : hipStream_t (NULL = default stream).  The launch is asynchronous.
+ */
+int ptamd_raytrace(ptamd_context* ctx, void* surface_rgba8, uint32_t scene_id, uint32_t cubemap_id,
+                   const ptamd_camera* cam, uint32_t width, uint32_t height, void* stream,
+                   float* temporal_framebuffer, int32_t moved, uint32_t post_id);
+
+typedef enum {
+  PTAMD_KERNEL_AUTO = 0,        /* BVH traversal (the shipped default) */
+  PTAMD_KERNEL_BRUTE_FORCE = 1, /* the reference algorithm: every face, LDS-staged, wave-uniform */
+  PTAMD_KERNEL_BVH = 2          /* stackless threaded BVH, LDS-staged nodes + triangles */
+} ptamd_kernel_kind;
+
+/* Explicit form used by the bench, the tests and the multi-GPU row split. */
+typedef struct {
+  void* surface_rgba8;
+  float* temporal_framebuffer;
+  void* stream;
+  ptamd_camera camera;
+  uint32_t scene_id, cubemap_id;
+  uint32_t width, height;      /* FULL frame size (seeds and ray generation use it) */
+  uint32_t row_begin, row_end; /* surface rows [row_begin, row_end) rendered by this call */
+  uint32_t frame_nb;           /* >= 1: the reference's `seed`; hash_seed = WangHash(frame_nb) */
+  uint32_t bounces;            /* iterations of the raytrace.cu:67 loop when !moved (reference: 3) */
+  int32_t moved;
+  uint32_t post_id;            /* 0 none, 1 grayscale, 2 sepia, 3 invert (raytrace.cu:327-357) */
+  uint32_t kernel;             /* ptamd_kernel_kind */
+  uint32_t band_local_buffers; /* 0: buffers are full-frame; 1: they hold only the row band */
+} ptamd_launch;
+
+int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch);
+int ptamd_reset_frame_counter(ptamd_context* ctx);
+uint32_t ptamd_wang_hash(uint32_t a); /* raytrace.cu:275-285 */
+
+/* ---- measurement / introspection ----------------------------------------------------- */
+
+typedef struct {
+  uint64_t rays;            /* intersect() calls */
+  uint64_t nodes_visited;   /* BVH nodes whose box was tested */
+  uint64_t tris_tested;     /* Moller-Trumbore tests issued */
+  uint64_t mesh_hits;       /* intersect() calls won by a mesh face (one 16 B texel fetch each) */
+  uint64_t nmap_hits;       /* of those, on normal-mapped materials (one 12 B fetch each) */
+  uint64_t samples;         /* pixels rendered */
+} ptamd_trace_stats;
+
+/* Renders like ptamd_raytrace_ex with an instrumented build of the selected kernel and
+ * returns exact traversal counts (synchronous; outputs are written as usual). */
+int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_trace_stats* out);
+
+typedef struct {
+  uint32_t n_faces, n_lights, n_nodes, n_leaves, max_leaf_size, depth;
+  uint32_t node_bytes, tri_bytes, lds_bytes_bvh, lds_bytes_brute;
+} ptamd_scene_info;
+int ptamd_scene_info_get(ptamd_context* ctx, uint32_t scene_id, ptamd_scene_info* out);
+
+/* Nearest-hit query on explicit rays through the device traversal (tests: BVH vs brute
+ * force equivalence).  rays: n * {dir.xyz, origin.xyz}; out: n * {kind, index, t bits, pad}. */
+int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel,
+                     const float* rays_host, uint32_t n, int32_t* out_host);
+
+/* Host mirror of the device BVH walk (same node/triangle records, same float operations),
+ * so the builder's "equals brute force" contract can be tested without a GPU.  This is a
+ * test hook for the acceleration structure only; it renders nothing.
+ * rays: n * {dir.xyz, origin.xyz}; out: n * {kind, index, t bits, 0};
+ * counters (optional): [0] += nodes visited, [1] += triangles tested. */
+int ptamd_host_bvh_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
+                         int32_t* out, uint64_t* counters);
+
+/* Plain device-memory helpers so that C/C++ hosts need not link HIP themselves. */
+int ptamd_device_alloc(ptamd_context* ctx, size_t bytes, void** out);
+int ptamd_device_free(ptamd_context* ctx, void* p);
+int ptamd_device_memset(ptamd_context* ctx, void* p, int value, size_t bytes, void* stream);
+int ptamd_device_to_host(ptamd_context* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int ptamd_stream_synchronize(ptamd_context* ctx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
