@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Msamples/s (and ms/frame) at 1920x1080, 4 spp, indoor.obj.
+
+One "step" = one frame of the hot path = `spp` consecutive static launches of the megakernel
+(frame seeds 1..spp) accumulating into a zeroed temporal framebuffer, with every input
+resident in HBM before the timed region starts.  1 sample = one execution of the reference
+kernel() for one pixel.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is split into
+contiguous pixel-row bands (cuda_pathtracer_amd.tiles), each rank renders its band with
+global-coordinate seeds, and the finished RGBA8 bands are gathered with one RCCL all-gather
+per frame.  The frame is fixed, so scaling is "strong".
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and, at N = 1,
+`cpu_baseline` (the CPU oracle timed on the host cores — a reported baseline, not the target).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 4, 4
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--bounces", type=int, default=BOUNCES)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "indoor.scene"))
+    ap.add_argument("--kernel", choices=["bvh", "brute"], default="bvh")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="PMC-derived HBM bytes per launch written by scripts/collect_traffic.py (optional)")
+    return ap.parse_args()
+
+
+def cpu_baseline(hs, cube, width, height, bounces, target_seconds):
+    """The oracle (a port of the reference algorithm: brute force over every face) on all host
+    cores, on a bounded sample of the SAME workload: whole-frame 1-spp launches (seeds 1, 2, ..)
+    until ~target_seconds of wall time or `SPP` launches."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import pt_oracle as O
+    cores = os.cpu_count() or 1
+    osc = O.OracleScene.from_host_scene(hs, cube)
+    ocam = O.camera_from_record(hs.camera)
+    # rows sample sized from a quick probe so that slow hosts stay bounded
+    t0 = time.perf_counter()
+    O.render(osc, ocam, width, height, spp=1, bounces=bounces, rows=(height // 2, height // 2 + 8), nthreads=cores)
+    probe = max(time.perf_counter() - t0, 1e-4)
+    rows_per_sec = 8.0 / probe
+    rows = int(min(height, max(16, rows_per_sec * target_seconds / 1.0)))
+    launches = 1
+    if rows >= height:
+        rows = height
+        launches = int(max(1, min(SPP, target_seconds // max(height / rows_per_sec, 1e-3))))
+    y0 = (height - rows) // 2
+    acc = np.zeros((height, width, 3), dtype=np.float32)
+    t0 = time.perf_counter()
+    O.render(osc, ocam, width, height, spp=launches, bounces=bounces, rows=(y0, y0 + rows), nthreads=cores, accum=acc)
+    dt = time.perf_counter() - t0
+    samples = rows * width * launches
+    return {"value": samples / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/pt_oracle.c (brute-force reference algorithm), rows [{y0},{y0 + rows}) of the "
+                      f"{width}x{height} frame, {launches} launch(es) of 1 spp, {bounces} bounces, "
+                      f"{cores} threads, {dt:.1f} s"}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import cuda_pathtracer_amd as P
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, H, spp, B = args.width, args.height, args.spp, args.bounces
+    kernel = P.KERNEL_BVH if args.kernel == "bvh" else P.KERNEL_BRUTE_FORCE
+    hs = P.HostScene.load(args.scene)
+    cube = P.cubemap_for_scene(hs)
+    ctx = P.Context(local_rank)
+    ctx.setup_function_tables()
+    sid = ctx.upload_scene(hs)
+    cid = ctx.upload_cubemap(cube)
+    info = ctx.scene_info(sid)
+
+    dev = torch.device("cuda", local_rank)
+    bg = P.BandGather(H, W, world, rank, dev) if world > 1 else None
+    y0, y1 = P.row_bands(H, world)[rank]
+    fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True)
+    stream = torch.cuda.current_stream()
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i_timed=None):
+        fr.accum.zero_()
+        if i_timed is not None:
+            ev0[i_timed].record(stream)
+        fr.render(spp=spp, bounces=B, kernel=kernel, stream=stream)
+        if i_timed is not None:
+            ev1[i_timed].record(stream)
+        if world > 1:
+            bg.gather(fr.surface)  # one RCCL all-gather of the RGBA8 bands per frame
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # kernel time from HIP events on the launch stream (average megakernel launch duration)
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(args.steps, 1) / spp
+
+    # exact traversal counts for the algorithmic-bytes figure (instrumented build, untimed)
+    stats = {k: 0 for k in ("rays", "nodes_visited", "tris_tested", "mesh_hits", "nmap_hits", "samples")}
+    scratch = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True)
+    for k in range(1, spp + 1):
+        l = ctx.make_launch(scratch.surface, scratch.accum, sid, cid, hs.camera_struct(), W, H, frame_nb=k,
+                            bounces=B, rows=(y0, y1), kernel=kernel, band_local_buffers=True)
+        s = ctx.raytrace_stats(l)
+        for key in stats:
+            stats[key] += s[key]
+    torch.cuda.synchronize()
+    # bytes/sample = 28 + 16*h_mesh + 12*h_nmap + T,
+    #   T(BVH) = nodes_visited*64 + tris_tested*48 + rays*n_lights*32 ; T(brute) = rays*(n_faces*36 + n_lights*32)
+    n_lights = info["n_lights"]
+    if kernel == P.KERNEL_BVH:
+        trav = stats["nodes_visited"] * info["node_bytes"] + stats["tris_tested"] * info["tri_bytes"] + stats["rays"] * n_lights * 32
+    else:
+        trav = stats["rays"] * (info["n_faces"] * 36 + n_lights * 32)
+    alg_bytes_frame = 28 * stats["samples"] + 16 * stats["mesh_hits"] + 12 * stats["nmap_hits"] + trav
+    alg_bytes_launch = alg_bytes_frame / spp
+    achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
+    compulsory_launch = 28 * (y1 - y0) * W + hs.scene_bytes()
+
+    checksum = int(fr.surface.to(torch.int64).sum().item())
+    samples_total = W * H * spp * args.steps
+    value = samples_total / dt / 1e6
+
+    if rank == 0:
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                with open(args.traffic_json) as f:
+                    tj = json.load(f)
+                if tj.get("kernel") == args.kernel and tj.get("workload") == f"{W}x{H}":
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/sec at 1920x1080, 4 spp, indoor.obj",
+            "value": round(value, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_frame": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic: assets/indoor.scene (reference asset; 1x1 textures, constant env as the reference loads it on Linux)",
+            "config": {"workload": f"indoor.obj {W}x{H} {spp} spp {B} bounces ({'configs[1]' if world == 1 else 'configs[2]'})",
+                       "kernel": args.kernel, "faces": info["n_faces"], "bvh_nodes": info["n_nodes"],
+                       "parallelism": f"rows/{world}" + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel": "pt_megakernel", "kernel_ms_per_launch": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+                         "algorithmic_bytes_per_sample": round(alg_bytes_frame / max(stats["samples"], 1), 1),
+                         "compulsory_hbm_bytes_per_launch": int(compulsory_launch),
+                         "compulsory_hbm_gbps": round(compulsory_launch / (kern_ms * 1e-3) / 1e9, 2),
+                         "note": "traversal bytes are served from LDS, not HBM; see DESIGN.md 'Roofline'",
+                         "nodes_per_ray": round(stats["nodes_visited"] / max(stats["rays"], 1), 2),
+                         "tris_per_ray": round(stats["tris_tested"] / max(stats["rays"], 1), 2),
+                         "rays_per_sample": round(stats["rays"] / max(stats["samples"], 1), 3)},
+            "rgba_checksum_rank0_band": checksum,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hs, cube, W, H, B, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,3 +29,32 @@ def row_bands(height: int, world_size: int, align: int = 1) -> List[Tuple[int, i
 
 def band_of_rank(height: int, world_size: int, rank: int, align: int = 1) -> Tuple[int, int]:
     return row_bands(height, world_size, align)[rank]
+
+
+class BandGather:
+    """One all-gather per frame of the finished RGBA8 row bands (torch.distributed: RCCL over
+    xGMI on GPUs, gloo in the CPU tests).  Buffers are allocated once; bands that differ by a
+    row are padded to the tallest band so a single fixed-size collective suffices."""
+
+    def __init__(self, height: int, width: int, world_size: int, rank: int, device, align: int = 1):
+        import torch
+        self.bands = row_bands(height, world_size, align)
+        self.rank, self.world = rank, world_size
+        self.max_rows = max(e - b for b, e in self.bands)
+        self.send = torch.zeros((self.max_rows, width, 4), dtype=torch.uint8, device=device)
+        self.recv = torch.zeros((world_size * self.max_rows, width, 4), dtype=torch.uint8, device=device)
+
+    def gather(self, band_surface, group=None):
+        """band_surface: uint8[rows_of_this_rank, W, 4].  Returns the padded gather buffer
+        (asynchronous with respect to the host on GPU streams)."""
+        import torch.distributed as dist
+        b, e = self.bands[self.rank]
+        self.send[: e - b].copy_(band_surface)
+        dist.all_gather_into_tensor(self.recv, self.send, group=group)
+        return self.recv
+
+    def assemble(self):
+        """Full frame uint8[H, W, 4] from the last gather (drops the padding rows)."""
+        import torch
+        parts = [self.recv[r * self.max_rows: r * self.max_rows + (e - b)] for r, (b, e) in enumerate(self.bands)]
+        return torch.cat(parts, dim=0)

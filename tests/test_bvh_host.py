@@ -1,0 +1,78 @@
+"""The acceleration structure's contract, on the CPU: the ordered stackless BVH walk (host
+mirror of the device traversal, same records and float ops) returns exactly what the
+reference's brute-force loop returns (intersection.cuh:179-196) — same face index, same t bits."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS
+from helpers import make_scene, random_rays, random_soup
+
+
+def lightless(O, P, hs):
+    return O.OracleScene(hs.faces, hs.mesh_sizes, hs.materials, hs.lights[:0], hs.textures, hs.texels,
+                         P.cubemap_from_color())
+
+
+@pytest.mark.parametrize("name", ["indoor", "crate_land", "color_sample", "island", "sss_crate"])
+def test_bvh_equals_brute_force_on_assets(P, O, name):
+    hs = P.HostScene.load(os.path.join(ASSETS, name + ".scene"))
+    rng = np.random.default_rng(7)
+    rays = random_rays(rng, 30000, extent=4.0)
+    # half of the rays start on surfaces, offset like the path tracer does (raytrace.cu:125-132)
+    f = hs.faces["vertices"][rng.integers(0, len(hs.faces), 15000)]
+    a, b = rng.uniform(size=(2, 15000, 1)).astype(np.float32)
+    flip = (a + b) > 1
+    a, b = np.where(flip, 1 - a, a), np.where(flip, 1 - b, b)
+    rays[:15000, 3:] = f[:, 0] + a * (f[:, 1] - f[:, 0]) + b * (f[:, 2] - f[:, 0]) + rays[:15000, :3] * np.float32(0.03)
+    want = O.intersect(lightless(O, P, hs), rays)
+    got, nodes, tris = P.host_bvh_trace(hs, rays)
+    np.testing.assert_array_equal(got, want)
+    assert (want[:, 0] == 1).sum() > 3000
+    assert tris < 0.2 * len(rays) * len(hs.faces)          # it actually culls
+
+
+def test_bvh_equals_brute_force_on_random_soup(P, O):
+    rng = np.random.default_rng(3)
+    hs = make_scene(P, random_soup(rng, 700))
+    rays = random_rays(rng, 20000)
+    np.testing.assert_array_equal(P.host_bvh_trace(hs, rays)[0], O.intersect(lightless(O, P, hs), rays))
+
+
+def test_ties_resolve_to_lowest_face_index(P, O):
+    """Coincident duplicates: the reference's strict `<` keeps the FIRST face in storage order."""
+    rng = np.random.default_rng(5)
+    base = random_soup(rng, 40)
+    tris = np.concatenate([base, base[::-1], base])          # every triangle three times, shuffled positions
+    hs = make_scene(P, tris)
+    rays = random_rays(rng, 20000)
+    want = O.intersect(lightless(O, P, hs), rays)
+    got = P.host_bvh_trace(hs, rays)[0]
+    np.testing.assert_array_equal(got, want)
+    hit = want[want[:, 0] == 1, 1]
+    assert len(hit) > 500 and (hit < 40).all()
+
+
+def test_degenerate_inputs(P, O):
+    rng = np.random.default_rng(9)
+    rays = random_rays(rng, 2000)
+    rays[:50, 0] = 0.0          # axis-parallel directions (inf slab reciprocals)
+    rays[50:100, 1:3] = 0.0
+    empty = make_scene(P, np.zeros((0, 3, 3), np.float32))
+    got = P.host_bvh_trace(empty, rays)[0]
+    assert (got[:, 0] == 0).all() and (got[:, 2].view(np.float32) == np.float32(100000.0)).all()
+    one = make_scene(P, np.float32([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]]))
+    np.testing.assert_array_equal(P.host_bvh_trace(one, rays)[0], O.intersect(lightless(O, P, one), rays))
+    # zero-area and NaN triangles never hit and must not poison the tree
+    tris = random_soup(rng, 64)
+    tris[3] = tris[3][0]
+    tris[10, 1, 2] = np.nan
+    weird = make_scene(P, tris)
+    np.testing.assert_array_equal(P.host_bvh_trace(weird, rays)[0], O.intersect(lightless(O, P, weird), rays))
+    # axis-aligned flat geometry: zero-thickness boxes
+    quad = np.float32([[[-1, 0, -1], [1, 0, -1], [1, 0, 1]], [[-1, 0, -1], [1, 0, 1], [-1, 0, 1]],
+                       [[-1, 0, -1], [1, 0, 1], [1, 0, -1]], [[-1, 0, -1], [-1, 0, 1], [1, 0, 1]]])
+    flat = make_scene(P, quad)
+    rays[:, 3:] *= 0.5
+    np.testing.assert_array_equal(P.host_bvh_trace(flat, rays)[0], O.intersect(lightless(O, P, flat), rays))

@@ -1,0 +1,67 @@
+"""The N > 1 path on CPU: world_size-2 gloo job that splits the frame into row bands
+(cuda_pathtracer_amd.tiles), renders each band on its own rank (the oracle stands in for the
+device renderer here — this test is about the split/gather logic) and gathers the RGBA8 bands
+exactly as bench.py does.  The assembled frame must be bit-identical to the single-rank frame."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_row_bands_partition(P):
+    for h in (1, 7, 135, 1080, 2160, 1081):
+        for w in (1, 2, 3, 4, 8):
+            for align in (1, 16):
+                bands = P.row_bands(h, w, align)
+                assert len(bands) == w and bands[0][0] == 0 and bands[-1][1] == h
+                for (b0, e0), (b1, e1) in zip(bands, bands[1:]):
+                    assert e0 == b1 and b0 <= e0
+                sizes = [e - b for b, e in bands]
+                if align == 1:
+                    assert max(sizes) - min(sizes) <= 1
+                assert all(b % align == 0 for b, _ in bands)
+    assert P.row_bands(1080, 8) == [(i * 135, (i + 1) * 135) for i in range(8)]
+    with pytest.raises(ValueError):
+        P.row_bands(10, 0)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path[:0] = [{root!r}, os.path.join({root!r}, "oracle")]
+    import numpy as np, torch, torch.distributed as dist
+    import cuda_pathtracer_amd as P, pt_oracle as O
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    W, H, spp, B = 64, 37, 2, 3
+    hs = P.HostScene.load(os.path.join({root!r}, "assets", "indoor.scene"))
+    cube = P.cubemap_for_scene(hs)
+    sc, cam = O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera)
+    bg = P.BandGather(H, W, world, rank, torch.device("cpu"))
+    y0, y1 = bg.bands[rank]
+    _, rgba = O.render(sc, cam, W, H, spp=spp, bounces=B, rows=(y0, y1), nthreads=2)
+    bg.gather(torch.from_numpy(rgba[y0:y1]))
+    if rank == 0:
+        np.save({out!r}, bg.assemble().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_split_and_gather_equals_single_rank(P, O, indoor, tmp_path):
+    out = str(tmp_path / "frame.npy")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)], env=env, cwd=ROOT,
+                          timeout=600)
+    frame = np.load(out)
+    cube = P.cubemap_for_scene(indoor)
+    _, want = O.render(O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera), 64, 37,
+                       spp=2, bounces=3)
+    np.testing.assert_array_equal(frame, want)

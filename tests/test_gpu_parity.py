@@ -1,0 +1,288 @@
+"""GPU parity tests proper: the HIP megakernel, called through the C-ABI, against the CPU oracle
+on the same inputs and against the committed golden fixtures.
+
+Tolerance: ZERO.  Accumulators (float32) and RGBA8 surfaces must be bit-identical — both sides
+execute the same IEEE binary32/binary64 operation sequence (DESIGN.md "Defined arithmetic").
+At BASELINE.json's full size (1920x1080, 4 spp, 4 bounces), where the oracle would take
+minutes, parity is carried by size-independent properties: BVH kernel == brute-force kernel
+(the reference algorithm, itself oracle-checked at small sizes), row-band splits == full frame,
+N spp == sum of N one-spp launches, and an oracle check of a crop of full-resolution rows.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, GOLDEN
+from golden.make_golden import ALL, CASES, textured_scene
+from helpers import make_scene, random_rays, random_soup, synthetic_cubemap
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_render(P, ctx, hs, cube, W, H, spp, bounces, kernel, moved=False, post_id=0, rows=None, band_local=False,
+               first_frame=1, ids=None):
+    import torch
+    sid, cid = ids if ids is not None else (ctx.upload_scene(hs), ctx.upload_cubemap(cube))
+    fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=rows, band_local=band_local)
+    for k in range(first_frame, first_frame + spp):
+        l = ctx.make_launch(fr.surface, fr.accum, sid, cid, hs.camera_struct(), W, H, frame_nb=k, bounces=bounces,
+                            moved=moved, post_id=post_id, rows=fr.rows, kernel=kernel, band_local_buffers=band_local)
+        ctx.raytrace_ex(l)
+    torch.cuda.synchronize()
+    return fr.accum.cpu().numpy(), fr.surface.cpu().numpy()
+
+
+def assert_same(acc, rgba, ref_acc, ref_rgba, what=""):
+    bad = (acc.view(np.uint32) != ref_acc.view(np.uint32)).any(axis=2)
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} accumulator pixels differ (first {np.argwhere(bad)[:3].tolist()})"
+    np.testing.assert_array_equal(rgba, ref_rgba, err_msg=what)
+
+
+KERNELS = ["bvh", "brute"]
+
+
+def kid(P, name):
+    return P.KERNEL_BVH if name == "bvh" else P.KERNEL_BRUTE_FORCE
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", ALL)
+def test_hip_equals_golden_and_oracle(P, O, gpu_ctx, name, kernel):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    if name.startswith("textured"):
+        hs, cube = textured_scene()
+    else:
+        hs = P.HostScene.load(os.path.join(ASSETS, CASES[name][0]))
+        cube = P.cubemap_for_scene(hs)
+    W, H, spp, B = int(g["W"]), int(g["H"]), int(g["spp"]), int(g["bounces"])
+    acc, rgba = gpu_render(P, gpu_ctx, hs, cube, W, H, spp, B, kid(P, kernel), moved=bool(g["moved"]), post_id=int(g["post_id"]))
+    assert_same(acc, rgba, g["accum"], g["rgba"], f"{name}/{kernel} vs golden")
+    ref_acc, ref_rgba = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), W, H,
+                                 spp=spp, bounces=B, moved=bool(g["moved"]), post_id=int(g["post_id"]))
+    assert_same(acc, rgba, ref_acc, ref_rgba, f"{name}/{kernel} vs oracle")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_config1_256x256_1spp_2bounces(P, O, gpu_ctx, indoor, kernel):
+    """BASELINE.json configs[0]: indoor, 256x256, 1 spp, 2 bounces."""
+    cube = P.cubemap_for_scene(indoor)
+    acc, rgba = gpu_render(P, gpu_ctx, indoor, cube, 256, 256, 1, 2, kid(P, kernel))
+    ref = O.render(O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera), 256, 256, spp=1, bounces=2)
+    assert_same(acc, rgba, *ref, f"config1/{kernel}")
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (15, 17), (16, 16), (33, 9), (130, 47)])
+def test_ragged_frame_sizes(P, O, gpu_ctx, indoor, W, H):
+    """Frames that are not multiples of the 16x16 tile, down to a single pixel (Q13 padded grid)."""
+    cube = P.cubemap_for_scene(indoor)
+    ref = O.render(O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera), W, H, spp=2, bounces=3)
+    for kernel in KERNELS:
+        acc, rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, 2, 3, kid(P, kernel))
+        assert_same(acc, rgba, *ref, f"{W}x{H}/{kernel}")
+
+
+def test_all_post_processes_and_deep_bounces(P, O, gpu_ctx):
+    hs = P.HostScene.load(os.path.join(ASSETS, "color_sample.scene"))   # has an ior 1.5 material: refraction branch
+    cube = synthetic_cubemap(np.random.default_rng(11), 4)               # bilinear env lookups
+    osc, ocam = O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera)
+    for post in (0, 1, 2, 3):
+        ref = O.render(osc, ocam, 48, 32, spp=2, bounces=8, post_id=post)
+        acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 8, P.KERNEL_BVH, post_id=post)
+        assert_same(acc, rgba, *ref, f"post {post}")
+
+
+def test_degenerate_scenes(P, O, gpu_ctx):
+    """Empty scene (env only), lights only, one triangle, faces with NaN tangents + normal maps."""
+    rng = np.random.default_rng(21)
+    cube = synthetic_cubemap(rng, 2)
+    lights = [((0.0, 0.5, 1.0), (1.0, 0.9, 0.8), 4.0, 0.8)]
+    cases = {
+        "empty": make_scene(P, np.zeros((0, 3, 3), np.float32)),
+        "lights_only": make_scene(P, np.zeros((0, 3, 3), np.float32), lights=lights),
+        "one_tri": make_scene(P, np.float32([[[-2, -2, 0], [2, -2, 0], [0, 2, 0]]]), lights=lights),
+    }
+    # degenerate UVs -> inf/NaN tangents feeding the normal-map path
+    tris = random_soup(rng, 24, extent=1.0, size=0.8)
+    uvs = np.zeros((24, 3, 2), np.float32)
+    cases["nan_tangent_nmap"] = make_scene(P, tris, uvs=uvs, materials=[(0, 1, 1.0)],
+                                           textures=[np.float32([[[0.5, 0.6, 0.7, 0.3]]]), rng.uniform(0, 1, (4, 4, 3)).astype(np.float32)],
+                                           lights=lights)
+    for name, hs in cases.items():
+        ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 40, 24, spp=2, bounces=4)
+        for kernel in KERNELS:
+            acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 40, 24, 2, 4, kid(P, kernel))
+            # NaN accumulators cannot occur (clamp maps NaN to 1.0, raytrace.cu:248), so bit compare is total
+            assert_same(acc, rgba, *ref, f"{name}/{kernel}")
+
+
+def test_reference_raytrace_entry_point_counts_frames(P, O, gpu_ctx, indoor):
+    """ptamd_raytrace == raytrace(): context-held frame counter (raytrace.cu:296-300), 3 bounces,
+    `moved` resets the counter and the accumulator (preview mode)."""
+    import torch
+    cube = P.cubemap_for_scene(indoor)
+    sid, cid = gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube)
+    W, H = 72, 40
+    dev = torch.device("cuda", 0)
+    surf = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    tfb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    cam = indoor.camera_struct()
+    gpu_ctx.reset_frame_counter()
+    for _ in range(3):
+        gpu_ctx.raytrace(surf, sid, cid, cam, W, H, None, tfb, False, 0)
+    torch.cuda.synchronize()
+    osc, ocam = O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera)
+    ref = O.render(osc, ocam, W, H, spp=3, bounces=3)
+    assert_same(tfb.cpu().numpy(), surf.cpu().numpy(), *ref, "3 static frames")
+    # camera moved: counter back to 1, preview sample replaces the accumulator
+    gpu_ctx.raytrace(surf, sid, cid, cam, W, H, None, tfb, True, 0)
+    torch.cuda.synchronize()
+    ref = O.render(osc, ocam, W, H, spp=1, bounces=3, moved=True)
+    assert_same(tfb.cpu().numpy(), surf.cpu().numpy(), *ref, "moved frame")
+    # then static again: frame 2 accumulates on top of the preview (reference behaviour)
+    gpu_ctx.raytrace(surf, sid, cid, cam, W, H, None, tfb, False, 0)
+    torch.cuda.synchronize()
+    acc = ref[0].copy()
+    ref2 = O.render(osc, ocam, W, H, spp=1, bounces=3, first_frame=2, accum=acc)
+    assert_same(tfb.cpu().numpy(), surf.cpu().numpy(), *ref2, "static frame after move")
+
+
+def test_row_band_split_is_bit_identical(P, gpu_ctx, indoor):
+    """Multi-GPU contract (L3): any split into row bands, full-frame or band-local buffers,
+    reproduces the single-launch frame bit for bit (global-coordinate seeds)."""
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    W, H, spp, B = 200, 121, 2, 4
+    full_acc, full_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
+    for world in (2, 3, 8):
+        accs, rgbas = [], []
+        for rows in P.row_bands(H, world):
+            a, r = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, rows=rows, band_local=True, ids=ids)
+            assert a.shape[0] == rows[1] - rows[0]
+            accs.append(a)
+            rgbas.append(r)
+        np.testing.assert_array_equal(np.concatenate(rgbas, axis=0), full_rgba)
+        # accumulator bands are stored row-flipped: band r covers tfb rows [H-e, H-b)
+        np.testing.assert_array_equal(np.concatenate(accs[::-1], axis=0).view(np.uint32), full_acc.view(np.uint32))
+    # full-frame buffers, band launches
+    import torch
+    fr = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H)
+    for k in range(1, spp + 1):
+        for rows in P.row_bands(H, 5):
+            gpu_ctx.raytrace_ex(gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), W, H, frame_nb=k,
+                                                    bounces=B, rows=rows, kernel=P.KERNEL_BVH))
+    torch.cuda.synchronize()
+    assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), full_acc, full_rgba, "band launches into full buffers")
+
+
+def test_trace_rays_device_equals_oracle(P, O, gpu_ctx):
+    """Nearest-hit records (kind, index, t bits) of both device traversals == brute-force oracle,
+    including light spheres."""
+    rng = np.random.default_rng(17)
+    for name in ("indoor", "island"):
+        hs = P.HostScene.load(os.path.join(ASSETS, name + ".scene"))
+        sid = gpu_ctx.upload_scene(hs)
+        rays = random_rays(rng, 50000, extent=3.5)
+        want = O.intersect(O.OracleScene.from_host_scene(hs, P.cubemap_from_color()), rays)
+        for k in (P.KERNEL_BVH, P.KERNEL_BRUTE_FORCE):
+            np.testing.assert_array_equal(gpu_ctx.trace_rays(sid, rays, k), want)
+        assert (want[:, 0] == 1).sum() > 5000
+    soup = make_scene(P, random_soup(rng, 3000, extent=3.0, size=0.25))       # does not fit in LDS: global-memory variant
+    sid = gpu_ctx.upload_scene(soup)
+    rays = random_rays(rng, 20000)
+    want = O.intersect(O.OracleScene.from_host_scene(soup, P.cubemap_from_color()), rays)
+    np.testing.assert_array_equal(gpu_ctx.trace_rays(sid, rays, P.KERNEL_BVH), want)
+
+
+def test_large_scene_uses_global_memory_variant(P, O, gpu_ctx):
+    """A scene whose traversal set exceeds the LDS budget renders through the L2-resident path."""
+    rng = np.random.default_rng(33)
+    hs = make_scene(P, random_soup(rng, 2500, extent=2.5, size=0.3),
+                    lights=[((0.0, 3.0, 1.0), (1, 1, 1), 6.0, 0.7)])
+    cube = synthetic_cubemap(rng, 4)
+    sid = gpu_ctx.upload_scene(hs)
+    info = gpu_ctx.scene_info(sid)
+    assert info["lds_bytes_bvh"] > 64 * 1024
+    ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 48, 32, spp=2, bounces=3)
+    acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 3, P.KERNEL_BVH)
+    assert_same(acc, rgba, *ref, "global-memory BVH")
+
+
+def test_full_size_properties_1080p_4spp_4bounces(P, O, gpu_ctx, indoor):
+    """BASELINE.json configs[1] at full size."""
+    import torch
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    W, H, spp, B = 1920, 1080, 4, 4
+    bvh_acc, bvh_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
+    # (1) the BVH walk returns the brute-force loop's result for every ray of every path
+    bf_acc, bf_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BRUTE_FORCE, ids=ids)
+    assert_same(bvh_acc, bvh_rgba, bf_acc, bf_rgba, "1080p BVH vs brute force")
+    # (2) N spp == sum of N one-spp launches
+    parts = [gpu_render(P, gpu_ctx, indoor, cube, W, H, 1, B, P.KERNEL_BVH, first_frame=k, ids=ids)[0] for k in (1, 2, 3, 4)]
+    np.testing.assert_array_equal(bvh_acc, ((parts[0] + parts[1]) + parts[2]) + parts[3])
+    # (3) idempotence: rendering again gives the same bits
+    again = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
+    assert_same(*again, bvh_acc, bvh_rgba, "re-render")
+    # (4) 8-way row split == full frame
+    rg = np.concatenate([gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, rows=r, band_local=True, ids=ids)[1]
+                         for r in P.row_bands(H, 8)], axis=0)
+    np.testing.assert_array_equal(rg, bvh_rgba)
+    # (5) oracle on full-resolution rows (a crop the CPU finishes in seconds)
+    rows = (536, 542)
+    acc = np.zeros((H, W, 3), np.float32)
+    ref_acc, ref_rgba = O.render(O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera), W, H,
+                                 spp=spp, bounces=B, rows=rows, accum=acc)
+    np.testing.assert_array_equal(bvh_rgba[rows[0]:rows[1]], ref_rgba[rows[0]:rows[1]])
+    np.testing.assert_array_equal(bvh_acc[H - rows[1]:H - rows[0]].view(np.uint32), ref_acc[H - rows[1]:H - rows[0]].view(np.uint32))
+    assert (bvh_rgba[..., 3] == 0).all() and bvh_acc.max() <= 4.0 and bvh_acc.min() >= 0.0
+    torch.cuda.synchronize()
+
+
+def test_stats_are_consistent(P, O, gpu_ctx, indoor):
+    """Instrumented launch: ray/mesh-hit counts equal the oracle's, BVH tests far fewer triangles."""
+    import torch
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    W, H = 96, 64
+    fr = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H)
+    l = gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), W, H, frame_nb=1, bounces=4, kernel=P.KERNEL_BVH)
+    s_bvh = gpu_ctx.raytrace_stats(l)
+    fr.reset()
+    l.kernel = P.KERNEL_BRUTE_FORCE
+    s_bf = gpu_ctx.raytrace_stats(l)
+    O.render(O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera), W, H, spp=1, bounces=4)
+    st = O.last_stats()
+    assert s_bvh["samples"] == s_bf["samples"] == W * H
+    assert s_bvh["rays"] == s_bf["rays"] == st["calls"]
+    assert s_bvh["mesh_hits"] == s_bf["mesh_hits"] == st["mesh_hits"]
+    assert s_bf["tris_tested"] >= s_bvh["tris_tested"] * 20 and s_bvh["nodes_visited"] > 0
+
+
+def test_error_behaviour(P, gpu_ctx, indoor):
+    """Bad arguments come back as status codes with a message; nothing is launched."""
+    import torch
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    fr = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), 32, 32)
+    def launch(**kw):
+        base = dict(frame_nb=1, bounces=3)
+        base.update(kw)
+        return gpu_ctx.make_launch(fr.surface, fr.accum, ids[0], ids[1], indoor.camera_struct(), 32, 32, **base)
+    for bad in (dict(frame_nb=0), dict(bounces=0), dict(post_id=4), dict(rows=(5, 40)), dict(rows=(9, 3)), dict(kernel=7)):
+        with pytest.raises(P.PtamdError) as e:
+            gpu_ctx.raytrace_ex(launch(**bad))
+        assert e.value.status == P.native.PTAMD_ERR_ARG
+    l = launch()
+    l.scene_id = 999
+    with pytest.raises(P.PtamdError):
+        gpu_ctx.raytrace_ex(l)
+    with pytest.raises(ValueError):
+        gpu_ctx.make_launch(torch.zeros(4), fr.accum, *ids, indoor.camera_struct(), 32, 32, frame_nb=1)   # CPU tensor
+    bad_scene = P.HostScene(indoor.faces.copy(), indoor.mesh_sizes, indoor.materials, indoor.lights, indoor.textures, indoor.texels)
+    bad_scene.faces["material_id"][3] = 77
+    with pytest.raises(P.PtamdError):
+        gpu_ctx.upload_scene(bad_scene)
+    # empty row band is a no-op
+    gpu_ctx.raytrace_ex(launch(rows=(7, 7)))
+    torch.cuda.synchronize()

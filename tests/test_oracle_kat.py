@@ -1,0 +1,271 @@
+"""Known-answer tests that pin the CPU oracle (oracle/pt_oracle.c).
+
+The reference ships no tests or golden vectors and cannot be built here, so these
+answers are derived by hand / by independent double-precision evaluation of the formulas the
+reference source states (file:line in each test).  Parity with the CUDA binary stays unpinned.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a, dtype=np.float32)
+    b64 = np.asarray(b, dtype=np.float64)
+    spacing = np.spacing(np.abs(b64).astype(np.float32)).astype(np.float64)
+    return np.abs(a.astype(np.float64) - b64) / spacing
+
+
+def py_wang_hash(a):  # raytrace.cu:275-285, independent restatement
+    m = 0xFFFFFFFF
+    a = ((a ^ 61) ^ (a >> 16)) & m
+    a = (a + (a << 3)) & m
+    a = (a ^ (a >> 4)) & m
+    a = (a * 0x27D4EB2D) & m
+    a = (a ^ (a >> 15)) & m
+    return a
+
+
+def test_wang_hash_kat(O, P):
+    # SURVEY §8-a2 values
+    expect = [0xC0A9496A, 0x27922C9D, 0xC6793575, 0x87D06FBE, 0xCC49325C, 0xC60AEE8D]
+    for i, e in enumerate(expect):
+        assert py_wang_hash(i) == e
+        assert O.wang_hash(i) == e
+        assert P.wang_hash(i) == e
+    for a in (0xFFFFFFFF, 0x80000000, 12345678, 61):
+        assert O.wang_hash(a) == py_wang_hash(a) == P.wang_hash(a)
+
+
+def py_xorwow(seed, n):
+    """cuRAND XORWOW as published (curand_kernel.h: curand_init scramble + xorwow step)."""
+    m = 0xFFFFFFFF
+    s0 = (seed ^ 0xAAD26B49) & m
+    s1 = 0xF7DCEFDD
+    t0 = (1099087573 * s0) & m
+    t1 = (2591861531 * s1) & m
+    v = [(123456789 + t0) & m, 362436069 ^ t0, (521288629 + t1) & m, 88675123 ^ t1, (5783321 + t0) & m]
+    d = (6615241 + t1 + t0) & m
+    out = []
+    for _ in range(n):
+        t = v[0] ^ (v[0] >> 2)
+        v = v[1:] + [((v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1))) & m]
+        d = (d + 362437) & m
+        out.append((v[4] + d) & m)
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 0xC0A9496A, 0xFFFFFFFF, 987654321])
+def test_xorwow_matches_published_algorithm(O, seed):
+    lib = O.load()
+    st = (C.c_uint32 * 6)()
+    lib.or_xorwow_init(seed, st)
+    got = [lib.or_xorwow_next(st) for _ in range(64)]
+    assert got == py_xorwow(seed, 64)
+
+
+def test_xorwow_uniform_range_and_formula(O):
+    lib = O.load()
+    st = (C.c_uint32 * 6)()
+    st2 = (C.c_uint32 * 6)()
+    lib.or_xorwow_init(42, st)
+    lib.or_xorwow_init(42, st2)
+    for _ in range(2000):
+        x = lib.or_xorwow_next(st2)
+        u = lib.or_xorwow_uniform(st)
+        # curand_uniform: x * 2^-32 + 2^-33 in binary32
+        e = np.float32(np.float32(x) * np.float32(2.0 ** -32)) + np.float32(2.0 ** -33)
+        assert np.float32(u) == e
+        assert 0.0 < u <= 1.0
+    # the extremes of the mapping: 0 -> 2^-33 (> 0), 0xffffffff -> 1.0
+    assert np.float32(np.float32(0xFFFFFFFF) * np.float32(2.0 ** -32)) + np.float32(2.0 ** -33) == np.float32(1.0)
+
+
+def test_sincos_accuracy(O):
+    lib = O.load()
+    s, c = C.c_float(), C.c_float()
+    xs = np.concatenate([np.linspace(0.0, 2 * math.pi, 20001), np.array([1e-8, 2 ** -33 * 2 * math.pi, 6.2831855])])
+    worst = 0.0
+    for x in xs.astype(np.float32):
+        lib.or_sincosf(float(x), C.byref(s), C.byref(c))
+        xs64 = float(x)
+        # absolute error near zeros of sin/cos is what matters there; elsewhere ulps
+        for got, ref in ((s.value, math.sin(xs64)), (c.value, math.cos(xs64))):
+            err = abs(got - ref)
+            assert err <= max(2.0 * float(np.spacing(np.float32(abs(ref)))), 1.2e-7), (x, got, ref)
+            worst = max(worst, err)
+    assert worst < 2.5e-7
+
+
+def test_powf_accuracy_and_special_cases(O):
+    lib = O.load()
+    g = float(np.float32(1.0 / 2.2))
+    xs = np.concatenate([np.linspace(0.0, 1.5, 5001), 10.0 ** np.linspace(-30, 3, 500)]).astype(np.float32)
+    for x in xs:
+        got = lib.or_powf(float(x), g)
+        ref = float(x) ** g
+        if ref == 0.0:
+            assert got == 0.0
+        else:
+            assert ulp_diff(got, ref) <= 0.5001, (x, got, ref)
+    for x in np.linspace(-1.0, 1.0, 401).astype(np.float32):  # raytrace.cu:163 powf(cos_theta, 5.0f)
+        got = lib.or_powf(float(x), 5.0)
+        ref = float(x) ** 5
+        assert (got == 0.0 and ref == 0.0) or ulp_diff(got, ref) <= 0.5001
+    assert lib.or_powf(0.0, g) == 0.0
+    assert lib.or_powf(1.0, 123.0) == 1.0
+    assert lib.or_powf(5.0, 0.0) == 1.0
+    assert math.isnan(lib.or_powf(-0.5, g))           # negative base, non-integer exponent
+    assert lib.or_powf(-2.0, 3.0) == -8.0 and lib.or_powf(-2.0, 2.0) == 4.0
+    assert math.isnan(lib.or_powf(float("nan"), g))
+    assert lib.or_powf(float("inf"), g) == float("inf")
+
+
+def _f3(O, v):
+    return O.F3(float(v[0]), float(v[1]), float(v[2]))
+
+
+def test_intersect_triangle_hand_cases(O):
+    """intersection.cuh:102-135: one-sided (det < 1e-7 rejects back faces), barycentric
+    interpolation of normals/uvs, uv wrapped by mod(uv, 1)."""
+    lib = O.load()
+    face = np.zeros(1, dtype=O.FACE_DTYPE)
+    face["vertices"][0] = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]
+    face["normals"][0] = [[0, 0, 1], [0, 0, 2], [0, 0, 4]]
+    face["texcoords"][0] = [[0, 0], [2, 0], [0, 4]]
+    n, uv = O.F3(), O.F2()
+    t, bu, bv = C.c_float(), C.c_float(), C.c_float()
+    d, o = _f3(O, (0, 0, -1)), _f3(O, (0.25, 0.25, 1.0))
+    assert lib.or_intersect_triangle(face.ctypes.data, C.byref(d), C.byref(o), C.byref(n), C.byref(uv),
+                                     C.byref(t), C.byref(bu), C.byref(bv)) == 1
+    assert (t.value, bu.value, bv.value) == (1.0, 0.25, 0.25)
+    assert n.z == 0.5 * 1 + 0.25 * 2 + 0.25 * 4                      # not normalised
+    assert (uv.x, uv.y) == (0.5, 0.0)                                 # (0.5, 1.0) wrapped: 1.0 - floor(1.0) = 0
+    # same ray from behind: culled
+    d, o = _f3(O, (0, 0, 1)), _f3(O, (0.25, 0.25, -1.0))
+    assert lib.or_intersect_triangle(face.ctypes.data, C.byref(d), C.byref(o), C.byref(n), C.byref(uv),
+                                     C.byref(t), C.byref(bu), C.byref(bv)) == 0
+    # outside: u + v > 1
+    d, o = _f3(O, (0, 0, -1)), _f3(O, (0.75, 0.75, 1.0))
+    assert lib.or_intersect_triangle(face.ctypes.data, C.byref(d), C.byref(o), C.byref(n), C.byref(uv),
+                                     C.byref(t), C.byref(bu), C.byref(bv)) == 0
+    # edge inclusive: u == 0 passes (u < 0 rejects), and a hit BEHIND the origin still returns 1 with t < 0
+    d, o = _f3(O, (0, 0, -1)), _f3(O, (0.0, 0.5, -2.0))
+    assert lib.or_intersect_triangle(face.ctypes.data, C.byref(d), C.byref(o), C.byref(n), C.byref(uv),
+                                     C.byref(t), C.byref(bu), C.byref(bv)) == 1
+    assert t.value == -2.0 and bu.value == 0.0
+    # unnormalised direction: t is in units of |dir| (Q4)
+    d, o = _f3(O, (0, 0, -0.5)), _f3(O, (0.25, 0.25, 1.0))
+    assert lib.or_intersect_triangle(face.ctypes.data, C.byref(d), C.byref(o), C.byref(n), C.byref(uv),
+                                     C.byref(t), C.byref(bu), C.byref(bv)) == 1
+    assert t.value == 2.0
+
+
+def test_intersect_sphere_quirks(O):
+    """intersection.cuh:140-155.  The conditional expression at :152 is a discarded value, so t
+    is b - disc when that is > 0.01 and b + disc OTHERWISE (never forced to 0)."""
+    lib = O.load()
+    light = O.Light(O.F3(1, 1, 1), O.F3(0, 0, 0), 2.0, 1.0)
+    t = C.c_float()
+    d, o = _f3(O, (0, 0, -1)), _f3(O, (0, 0, 3))
+    assert lib.or_intersect_sphere(C.byref(d), C.byref(o), C.byref(light), C.byref(t)) == 1 and t.value == 2.0
+    # origin inside, close under the surface: far root 0.005 <= epsilon is still returned
+    d, o = _f3(O, (0, 0, 1)), _f3(O, (0, 0, 0.995))
+    assert lib.or_intersect_sphere(C.byref(d), C.byref(o), C.byref(light), C.byref(t)) == 1
+    assert abs(t.value - 0.005) < 1e-6
+    # sphere entirely behind the ray: both roots negative, function still says "hit" with t < 0
+    d, o = _f3(O, (0, 0, 1)), _f3(O, (0, 0, 3))
+    assert lib.or_intersect_sphere(C.byref(d), C.byref(o), C.byref(light), C.byref(t)) == 1 and t.value == -2.0
+    # miss
+    d, o = _f3(O, (0, 0, -1)), _f3(O, (2, 0, 3))
+    assert lib.or_intersect_sphere(C.byref(d), C.byref(o), C.byref(light), C.byref(t)) == 0
+
+
+def test_exposure_kat(O):
+    """post_process.cuh:14-41, evaluated independently in float64."""
+    lib = O.load()
+
+    def tm(x):
+        A, B, Cc, D, E, F = 0.15, 0.50, 0.10, 0.20, 0.02, 0.30
+        return ((x * (A * x + Cc * B) + D * E) / (x * (A * x + B) + D * F)) - E / F
+
+    out = (C.c_float * 3)()
+    for v in (0.0, 0.01, 0.25, 0.5, 1.0):
+        lib.or_exposure((C.c_float * 3)(v, v, v), out)
+        ref = tm(2.0 * v) / tm(11.2)
+        assert abs(out[0] - ref) < 2e-6 and out[0] == out[1] == out[2]
+    lib.or_exposure((C.c_float * 3)(0.5, 0.5, 0.5), out)
+    assert abs(out[0] - 0.304301) < 1e-6
+    lib.or_exposure((C.c_float * 3)(1.0, 1.0, 1.0), out)
+    assert int((out[0] ** (1 / 2.2)) * 255) == 184   # RGBA8 never saturates
+
+
+def test_pack_and_post_process(O):
+    lib = O.load()
+    assert lib.or_pack_rgba((C.c_float * 3)(1.0, 0.5, 0.0)) == (255 | (127 << 8))
+    assert lib.or_pack_rgba((C.c_float * 3)(float("nan"), -0.2, 0.999)) == (254 << 16)
+    assert lib.or_pack_rgba((C.c_float * 3)(1.01, 2.0, 0.0)) == ((257 & 255) | ((510 & 255) << 8))  # 8-bit field wraps
+    out = (C.c_float * 3)()
+    c = (C.c_float * 3)(0.2, 0.4, 0.6)
+    lib.or_post_process(0, c, out)
+    assert list(out) == list(c)
+    lib.or_post_process(1, c, out)
+    g = np.float32(np.float64(np.float32(0.2)) * 0.3 + np.float64(np.float32(0.4)) * 0.59 + np.float64(np.float32(0.6)) * 0.11)
+    assert out[0] == out[1] == out[2] == g
+    lib.or_post_process(3, c, out)
+    assert out[0] == np.float32(1.0 - np.float64(np.float32(0.2)))
+    lib.or_post_process(2, c, out)
+    assert out[0] == np.float32(np.float64(np.float32(0.2)) * 0.393 + np.float64(np.float32(0.4)) * 0.769 + np.float64(np.float32(0.6)) * 0.189)
+
+
+def test_generate_ray_centre_and_axes(O):
+    """intersection.cuh:75-97: the centre pixel looks along cam.dir; +x on screen is -normalize(cross(dir, down))."""
+    lib = O.load()
+    cam = O.Camera()
+    cam.position = O.F3(1, 2, 3)
+    cam.dir = O.F3(0, 0, -1)
+    cam.fov_x = math.pi / 2
+    d, o = O.F3(), O.F3()
+    lib.or_generate_ray(8, 8, 8, 8, C.byref(cam), C.byref(d), C.byref(o))
+    assert (o.x, o.y, o.z) == (1, 2, 3)
+    assert abs(d.x) < 1e-6 and abs(d.y) < 1e-6 and abs(d.z + 1) < 1e-6
+    # generateRay overwrote u/v: u = -normalize(cross(dir,(0,-1,0))) = (1,0,0); v = normalize(cross(u_before_negation, dir))
+    assert (cam.u.x, cam.u.y, cam.u.z) == (1.0, 0.0, 0.0)
+    assert (cam.v.x, cam.v.y, cam.v.z) == (0.0, -1.0, 0.0)
+    # fov 90 deg: pixel at x = 2*half_w is 45 degrees to the right
+    lib.or_generate_ray(16, 8, 8, 8, C.byref(cam), C.byref(d), C.byref(o))
+    assert abs(d.x - math.sqrt(0.5)) < 1e-6 and abs(d.z + math.sqrt(0.5)) < 1e-6
+    # y grows DOWN the picture: row 0 looks up (+y world)
+    lib.or_generate_ray(8, 0, 8, 8, C.byref(cam), C.byref(d), C.byref(o))
+    assert d.y > 0.5
+
+
+def test_cubemap_face_selection_and_filter(O, P):
+    from helpers import make_scene
+    hs = make_scene(P, np.zeros((0, 3, 3), np.float32))
+    cube = np.zeros((6, 2, 2, 4), np.float32)
+    for f in range(6):
+        cube[f, :, :, :3] = f + 1
+    sc = O.OracleScene.from_host_scene(hs, cube)
+    lib = O.load()
+    out = (C.c_float * 4)()
+    # CUDA cubemap table: +x,-x,+y,-y,+z,-z ; ties resolved x, then y, then z
+    for vec, face in (((1, 0.2, 0.1), 0), ((-1, 0.2, 0.1), 1), ((0.1, 1, 0.2), 2), ((0.1, -1, 0.2), 3),
+                      ((0.1, 0.2, 1), 4), ((0.1, 0.2, -1), 5), ((1, 1, 1), 0), ((0, 1, 1), 2)):
+        lib.or_tex_cubemap(C.byref(sc.c), *[float(v) for v in vec], out)
+        assert out[0] == face + 1, (vec, out[0])
+    # bilinear with 8-bit weights inside one face: face +z, 2x2 texels 0,1 / 2,3 in channel 0
+    cube[4, :, :, 0] = [[0, 1], [2, 3]]
+    sc = O.OracleScene.from_host_scene(hs, cube)
+    lib.or_tex_cubemap(C.byref(sc.c), 0.0, 0.0, 1.0, out)        # centre: u = v = 0.5 -> xb = 0.5 -> a = b = 0.5
+    assert out[0] == 1.5
+    lib.or_tex_cubemap(C.byref(sc.c), -0.999, 0.999, 1.0, out)   # corner (s,t) ~ (-1,-1): clamped to texel (0,0)
+    assert out[0] == 0.0
+    # 1x1 cubemap returns the texel exactly
+    c1 = P.cubemap_from_color(0x131B23)
+    sc = O.OracleScene.from_host_scene(hs, c1)
+    lib.or_tex_cubemap(C.byref(sc.c), 0.3, -0.2, 0.9, out)
+    assert [out[0], out[1], out[2], out[3]] == [np.float32(19) / np.float32(255), np.float32(27) / np.float32(255),
+                                                 np.float32(35) / np.float32(255), 0.0]
