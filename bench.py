@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--bounces", type=int, default=BOUNCES)
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "indoor.scene"))
-    ap.add_argument("--kernel", choices=["bvh", "brute"], default="bvh")
+    ap.add_argument("--kernel", choices=["persistent", "bvh", "blockwise", "brute"], default="persistent")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -103,7 +103,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
-    kernel = P.KERNEL_BVH if args.kernel == "bvh" else P.KERNEL_BRUTE_FORCE
+    kernel = {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
+              "blockwise": P.KERNEL_BVH_BLOCKWISE}[args.kernel]
     hs = P.HostScene.load(args.scene)
     cube = P.cubemap_for_scene(hs)
     ctx = P.Context(local_rank)
@@ -165,7 +166,7 @@ def main():
     # bytes/sample = 28 + 16*h_mesh + 12*h_nmap + T,
     #   T(BVH) = nodes_visited*64 + tris_tested*48 + rays*n_lights*32 ; T(brute) = rays*(n_faces*36 + n_lights*32)
     n_lights = info["n_lights"]
-    if kernel == P.KERNEL_BVH:
+    if kernel != P.KERNEL_BRUTE_FORCE:
         trav = stats["nodes_visited"] * info["node_bytes"] + stats["tris_tested"] * info["tri_bytes"] + stats["rays"] * n_lights * 32
     else:
         trav = stats["rays"] * (info["n_faces"] * 36 + n_lights * 32)
@@ -200,7 +201,7 @@ def main():
                        "parallelism": f"rows/{world}" + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "pt_megakernel", "kernel_ms_per_launch": round(kern_ms, 4),
+                         "kernel": {"persistent": "pt_megakernel_persistent", "blockwise": "pt_megakernel_blockwise"}.get(args.kernel, "pt_megakernel"), "kernel_ms_per_launch": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes_launch),
                          "algorithmic_bytes_per_sample": round(alg_bytes_frame / max(stats["samples"], 1), 1),
                          "compulsory_hbm_bytes_per_launch": int(compulsory_launch),

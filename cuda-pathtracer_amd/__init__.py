@@ -6,7 +6,8 @@ this package is the thin host mirror of the reference interface.  The directory 
 carries a hyphen; import it as `cuda_pathtracer_amd` (alias module at the repo root).
 """
 from . import native
-from .native import (KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, PtamdError)
+from .native import (KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, KERNEL_BVH_PERSISTENT, KERNEL_BVH_BLOCKWISE,
+                     PtamdError)
 from .scene import (HostScene, cubemap_for_scene, cubemap_from_color, cubemap_from_cross,
                     FACE_DTYPE, MATERIAL_DTYPE, LIGHT_DTYPE, TEXTURE_DTYPE, CAMERA_DTYPE)
 from .render import (Context, FrameRenderer, host_bvh_trace, wang_hash, REFERENCE_BOUNCES,

@@ -22,6 +22,27 @@
 
 namespace ptamd {
 
+#ifndef PT_TILE_THREADS
+#define PT_TILE_THREADS 512
+#endif
+#ifndef PT_TILE_WAVES_PER_EU
+#define PT_TILE_WAVES_PER_EU 6
+#endif
+#ifndef PT_BW_THREADS
+#define PT_BW_THREADS 512
+#endif
+#ifndef PT_BW_WAVES_PER_EU
+#define PT_BW_WAVES_PER_EU 4
+#endif
+#ifndef PT_BW_FETCH_MIN
+#define PT_BW_FETCH_MIN 16u
+#endif
+#ifndef PT_PERSISTENT_WAVES_PER_EU
+#define PT_PERSISTENT_WAVES_PER_EU 6
+#endif
+#ifndef PT_PERSISTENT_THREADS
+#define PT_PERSISTENT_THREADS 512
+#endif
 #define PT_MAX_DIST 100000.0f
 #define PT_END 0xFFFFFFFFu
 
@@ -39,7 +60,9 @@ PT_DEV void mt_test(float4 a, float4 b, float4 c, f3 o, f3 d, Best& best)
   const f3 e2 = mk3(b.z, b.w, c.x);
   const f3 p_vec = cross(d, e2);
   const float det = dot(e1, p_vec);
-  if ((double)det < 0.0000001) return;
+  // intersection.cuh:110 compares in double: (double)det < 1e-7.  1e-7f is the float nearest to
+  // (and above) the double 1e-7 and no float lies between them, so `det < 1e-7f` decides identically.
+  if (det < 1e-7f) return;
   const float inv_det = 1.0f / det;
   const f3 t_vec = o - v0;
   const float u = dot(t_vec, p_vec) * inv_det;
@@ -69,48 +92,107 @@ PT_DEV void traverse_brute(const float4* tris, uint32_t n_faces, f3 o, f3 d, Bes
 }
 
 // Stackless ordered threaded BVH walk (layout: host/ptamd_internal.h).
+// The box test only has to be CONSERVATIVE (never cull the winner), not bit-reproducible, so it
+// uses v_rcp_f32 and one fma per slab plane; boxes carry a 1 mm margin that dwarfs its rounding
+// (DESIGN.md "Conservative boxes").  Everything that decides the RESULT — Moller-Trumbore and
+// the (t, index) minimum — is the reference's exact operation sequence (mt_test).
+struct Walk {
+  f3 o, d, inv, noi; // ray, 1/d, -o/d
+  uint32_t link_off; // dword offset of this ray's octant inside a node's miss-link table
+  uint32_t oct;
+  uint32_t node;     // next node to test, PT_END when the walk is over
+  Best best;
+};
+
+PT_DEV void walk_init(Walk& w, f3 o, f3 d, uint32_t n_nodes)
+{
+  w.o = o; w.d = d;
+  w.oct = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+  // a zero component would make lo*inv - o*inv an inf - inf; a denormal-sized stand-in keeps the
+  // slab arithmetic finite and classifies "origin inside/outside the slab" the same way
+  const float tiny = 1e-30f;
+  const float dx = __builtin_fabsf(d.x) < tiny ? __builtin_copysignf(tiny, d.x) : d.x;
+  const float dy = __builtin_fabsf(d.y) < tiny ? __builtin_copysignf(tiny, d.y) : d.y;
+  const float dz = __builtin_fabsf(d.z) < tiny ? __builtin_copysignf(tiny, d.z) : d.z;
+  w.inv = mk3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
+  w.noi = mk3(-(o.x * w.inv.x), -(o.y * w.inv.y), -(o.z * w.inv.z));
+  w.link_off = 8u + w.oct;
+  w.node = n_nodes ? 0u : PT_END;
+  w.best.t = PT_MAX_DIST; w.best.u = 0.f; w.best.v = 0.f; w.best.idx = PT_END;
+}
+
+// Box tests until this lane holds a leaf (leaf_count != 0) or its walk is over.
+template <bool STATS>
+PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count,
+                         uint32_t& n_nodes_visited, uint32_t& wave_node_iters)
+{
+  const float* links = reinterpret_cast<const float*>(nodes) + w.link_off;
+  leaf_first = 0;
+  leaf_count = 0;
+  uint32_t node = w.node;
+  while (node != PT_END) {
+    const float4 q0 = nodes[node * 4 + 0];
+    const float4 q1 = nodes[node * 4 + 1];
+    const uint32_t miss = f_as_u(links[node * 16]);
+    if (STATS) {
+      ++n_nodes_visited;
+      // one lane per executing wave counts the wave-level iteration (lane utilisation = nodes / (64 * iters))
+      const unsigned long long act = __ballot(1);
+      if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) ++wave_node_iters;
+    }
+    const float t0x = __builtin_fmaf(q0.x, w.inv.x, w.noi.x), t1x = __builtin_fmaf(q1.x, w.inv.x, w.noi.x);
+    const float t0y = __builtin_fmaf(q0.y, w.inv.y, w.noi.y), t1y = __builtin_fmaf(q1.y, w.inv.y, w.noi.y);
+    const float t0z = __builtin_fmaf(q0.z, w.inv.z, w.noi.z), t1z = __builtin_fmaf(q1.z, w.inv.z, w.noi.z);
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
+                                        __builtin_fminf(t0z, t1z));
+    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
+                                       __builtin_fmaxf(t0z, t1z));
+    const bool hit = tnear <= tfar && tfar >= 0.0f && tnear <= w.best.t;
+    const uint32_t info = f_as_u(q0.w);
+    const uint32_t child = f_as_u(q1.w);
+    const uint32_t count = info >> 24;
+    const uint32_t down = ((w.oct >> (child >> 30)) & 1u) ? (child & 0x3FFFFFFFu) : node + 1u;
+    node = (hit && count == 0u) ? down : miss;
+    if (hit && count != 0u) {
+      leaf_first = info & 0xFFFFFFu;
+      leaf_count = count;
+      break;
+    }
+  }
+  w.node = node;
+}
+
+template <bool STATS>
+PT_DEV void walk_leaf(const float4* tris, Walk& w, uint32_t leaf_first, uint32_t leaf_count, uint32_t& n_tris,
+                      uint32_t& wave_tri_iters)
+{
+  for (uint32_t k = 0; k < leaf_count; ++k) {
+    if (STATS) {
+      const unsigned long long act = __ballot(1);
+      if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) ++wave_tri_iters;
+    }
+    const uint32_t ti = (leaf_first + k) * 3;
+    mt_test<false>(tris[ti], tris[ti + 1], tris[ti + 2], w.o, w.d, w.best);
+  }
+  if (STATS) n_tris += leaf_count;
+}
+
+// "while-while": all lanes walk boxes until each holds a leaf (or is done), then all lanes run
+// Moller-Trumbore on their leaf, repeat.
 template <bool STATS>
 PT_DEV void traverse_bvh(const float4* nodes, const float4* tris, uint32_t n_nodes, f3 o, f3 d,
-                         Best& best, uint32_t& n_nodes_visited, uint32_t& n_tris)
+                         Best& best, uint32_t& n_nodes_visited, uint32_t& n_tris, uint32_t& wave_node_iters,
+                         uint32_t& wave_tri_iters)
 {
-  const uint32_t oct = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
-  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const float* links = reinterpret_cast<const float*>(nodes) + 8 + oct;
-  uint32_t node = n_nodes ? 0u : PT_END;
+  Walk w;
+  walk_init(w, o, d, n_nodes);
   for (;;) {
-    uint32_t leaf_first = 0, leaf_count = 0;
-    while (node != PT_END) {
-      const float4 q0 = nodes[node * 4 + 0];
-      const float4 q1 = nodes[node * 4 + 1];
-      const uint32_t miss = f_as_u(links[node * 16]);
-      if (STATS) ++n_nodes_visited;
-      const float t0x = (q0.x - o.x) * inv.x, t1x = (q1.x - o.x) * inv.x;
-      const float t0y = (q0.y - o.y) * inv.y, t1y = (q1.y - o.y) * inv.y;
-      const float t0z = (q0.z - o.z) * inv.z, t1z = (q1.z - o.z) * inv.z;
-      const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                                          __builtin_fminf(t0z, t1z));
-      const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
-                                         __builtin_fmaxf(t0z, t1z));
-      const bool hit = tnear <= tfar * 1.0000005f && tfar >= 0.0f && tnear <= best.t;
-      const uint32_t info = f_as_u(q0.w);
-      const uint32_t count = info >> 24;
-      if (hit && count) {
-        leaf_first = info & 0xFFFFFFu;
-        leaf_count = count;
-        node = miss;
-        break;
-      }
-      const uint32_t child = f_as_u(q1.w);
-      const uint32_t down = ((oct >> (child >> 30)) & 1u) ? (child & 0x3FFFFFFFu) : node + 1u;
-      node = hit ? down : miss;
-    }
+    uint32_t leaf_first, leaf_count;
+    walk_to_leaf<STATS>(nodes, w, leaf_first, leaf_count, n_nodes_visited, wave_node_iters);
     if (leaf_count == 0) break;
-    for (uint32_t k = 0; k < leaf_count; ++k) {
-      const uint32_t ti = (leaf_first + k) * 3;
-      mt_test<false>(tris[ti], tris[ti + 1], tris[ti + 2], o, d, best);
-    }
-    if (STATS) n_tris += leaf_count;
+    walk_leaf<STATS>(tris, w, leaf_first, leaf_count, n_tris, wave_tri_iters);
   }
+  best = w.best;
 }
 
 // intersection.cuh:140-155 (see the oracle's note on the discarded conditional at :152)
@@ -135,76 +217,90 @@ PT_DEV int texture_idx(const TexDesc& tex, float uvx, float uvy)
   return (y * tex.w + x) * tex.nb_chan;
 }
 
-struct Counters { uint32_t rays, nodes, tris, mesh_hits, nmap_hits; };
+struct Counters { uint32_t rays, nodes, tris, mesh_hits, nmap_hits, wave_node_iters, wave_tri_iters; };
 
-// intersection.cuh:161-246.  KIND: 1 brute force, 2 BVH.
+// Result of the nearest-hit search of one intersect() call, before any shading data is touched:
+// 16 bytes, which is what travels through LDS when rays are compacted across a workgroup.
+// idx: global face index; PT_END = nothing; PT_LIGHT | l = light sphere l won.
+struct Nearest { float t, u, v; uint32_t idx; };
+#define PT_LIGHT 0x80000000u
+
+// The light loop of intersect() (intersection.cuh:199-212) applied to the face search's result.
+PT_DEV Nearest nearest_lights(const KParams& p, f3 o, f3 d, Nearest n)
+{
+  for (uint32_t l = 0; l < p.n_lights; ++l) {
+    const float4 la = p.lights[l * 2 + 0], lb = p.lights[l * 2 + 1];
+    float t;
+    if (intersect_sphere(o, d, mk3(la.w, lb.x, lb.y), lb.w, t) && t < n.t && t >= 0.0f) {
+      n.t = t;
+      n.idx = PT_LIGHT | l;
+    }
+  }
+  return n;
+}
+
+// First half of intersection.cuh:161-246: the two search loops (faces :179-196, lights :199-212).
+// KIND: 1 brute force, 2 BVH.
 template <int KIND, bool STATS>
-PT_DEV bool intersect(const KParams& p, const float4* s_nodes, const float4* s_tris, f3 o, f3 d,
-                      Hit& hit, Counters& cnt)
+PT_DEV Nearest trace_nearest(const KParams& p, const float4* s_nodes, const float4* s_tris, f3 o, f3 d,
+                             Counters& cnt)
 {
   Best best;
   best.t = PT_MAX_DIST; best.u = 0.f; best.v = 0.f; best.idx = PT_END;
-  hit.dist = PT_MAX_DIST;
   if (STATS) cnt.rays++;
   if (KIND == 1) traverse_brute<STATS>(s_tris, p.n_faces, o, d, best, cnt.tris);
-  else traverse_bvh<STATS>(s_nodes, s_tris, p.n_nodes, o, d, best, cnt.nodes, cnt.tris);
+  else traverse_bvh<STATS>(s_nodes, s_tris, p.n_nodes, o, d, best, cnt.nodes, cnt.tris, cnt.wave_node_iters, cnt.wave_tri_iters);
+  Nearest n;
+  n.t = best.t; n.u = best.u; n.v = best.v; n.idx = best.idx;
+  return nearest_lights(p, o, d, n);
+}
 
-  const bool mesh_hit = best.idx != PT_END;
-  f3 surface_normal = mk3(0.f), tangent = mk3(0.f);
-  float uvx = 0.f, uvy = 0.f;
-  int mat_id = -1;
-  if (mesh_hit) {
-    // deferred part of intersectTriangle (intersection.cuh:124-131) for the winner only
-    const float4* sh = p.shade + (size_t)best.idx * 5;
-    const float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3], s4 = sh[4];
-    const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
-    const float u = best.u, v = best.v;
-    const float w = 1.0f - u - v;
-    const f3 nrm = w * n0 + u * n1 + v * n2;
-    const float ux = w * s2.y + u * s2.w + v * s3.y;
-    const float uy = w * s2.z + u * s3.x + v * s3.z;
-    uvx = ux - __builtin_floorf(ux / 1.0f); // mod(uv, 1.0): cutils_math.h:1728-1737
-    uvy = uy - __builtin_floorf(uy / 1.0f);
-    tangent = mk3(s3.w, s4.x, s4.y);
-    mat_id = (int)f_as_u(s4.z);
-    hit.normal = nrm;
-    surface_normal = nrm;
-    hit.dist = best.t;
-    hit.light = -1;
-  }
-
-  for (uint32_t l = 0; l < p.n_lights; ++l) {
+// Second half of intersection.cuh:161-246 for the winner only: the deferred interpolation of
+// intersectTriangle (:124-131), the light normal (:204-210), texture and normal-map fetches
+// (:216-243).  Returns intersection.dist < MAX_DIST.
+template <bool STATS>
+PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& cnt)
+{
+  hit.dist = n.t;
+  if (n.idx == PT_END) return false; // n.t == MAX_DIST
+  if (n.idx & PT_LIGHT) {
+    const uint32_t l = n.idx & ~PT_LIGHT;
     const float4 la = p.lights[l * 2 + 0], lb = p.lights[l * 2 + 1];
-    const f3 center = mk3(la.w, lb.x, lb.y);
-    float t;
-    if (intersect_sphere(o, d, center, lb.w, t) && t < hit.dist && t >= 0.0f) {
-      hit.light = (int)l;
-      hit.dist = t;
-      hit.diffuse_col = mk3(la.x, la.y, la.z);
-      hit.normal = normalize(center - (t * d)); // intersection.cuh:208: origin ignored
-      mat_id = -1;
-    }
+    hit.light = (int)l;
+    hit.diffuse_col = mk3(la.x, la.y, la.z);
+    hit.normal = normalize(mk3(la.w, lb.x, lb.y) - (n.t * d)); // intersection.cuh:208: origin ignored
+    return hit.dist < PT_MAX_DIST;
   }
-
-  if (mat_id >= 0) {
-    const int4 m = p.materials[mat_id];
-    hit.ior = u_as_f((uint32_t)m.z);
-    const TexDesc tex = p.textures[m.x];
-    const float* texel = p.texels + tex.offset + texture_idx(tex, uvx, uvy);
-    hit.diffuse_col = mk3(texel[0], texel[1], texel[2]);
-    hit.specular_col = texel[3];
-    if (STATS) cnt.mesh_hits++;
-    if (m.y >= 0) {
-      const TexDesc nt = p.textures[m.y];
-      const float* nx = p.texels + nt.offset + texture_idx(nt, uvx, uvy);
-      const f3 n = normalize((mk3(nx[0], nx[1], nx[2]) * 2.0f) - 1.0f);
-      const f3 binormal = normalize(cross(tangent, surface_normal));
-      const f3 tx = tangent, ty = -binormal, tz = surface_normal;
-      hit.normal = mk3(tx.x * n.x + ty.x * n.y + tz.x * n.z,
-                       tx.y * n.x + ty.y * n.y + tz.y * n.z,
-                       tx.z * n.x + ty.z * n.y + tz.z * n.z);
-      if (STATS) cnt.nmap_hits++;
-    }
+  const float4* sh = p.shade + (size_t)n.idx * 5;
+  const float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3], s4 = sh[4];
+  const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+  const float u = n.u, v = n.v;
+  const float w = 1.0f - u - v;
+  const f3 surface_normal = w * n0 + u * n1 + v * n2;
+  const float ux = w * s2.y + u * s2.w + v * s3.y;
+  const float uy = w * s2.z + u * s3.x + v * s3.z;
+  const float uvx = ux - __builtin_floorf(ux / 1.0f); // mod(uv, 1.0): cutils_math.h:1728-1737
+  const float uvy = uy - __builtin_floorf(uy / 1.0f);
+  const f3 tangent = mk3(s3.w, s4.x, s4.y);
+  hit.normal = surface_normal;
+  hit.light = -1;
+  const int4 m = p.materials[f_as_u(s4.z)];
+  hit.ior = u_as_f((uint32_t)m.z);
+  const TexDesc tex = p.textures[m.x];
+  const float* texel = p.texels + tex.offset + texture_idx(tex, uvx, uvy);
+  hit.diffuse_col = mk3(texel[0], texel[1], texel[2]);
+  hit.specular_col = texel[3];
+  if (STATS) cnt.mesh_hits++;
+  if (m.y >= 0) {
+    const TexDesc nt = p.textures[m.y];
+    const float* nx = p.texels + nt.offset + texture_idx(nt, uvx, uvy);
+    const f3 nn = normalize((mk3(nx[0], nx[1], nx[2]) * 2.0f) - 1.0f);
+    const f3 binormal = normalize(cross(tangent, surface_normal));
+    const f3 tx = tangent, ty = -binormal, tz = surface_normal;
+    hit.normal = mk3(tx.x * nn.x + ty.x * nn.y + tz.x * nn.z,
+                     tx.y * nn.x + ty.y * nn.y + tz.y * nn.z,
+                     tx.z * nn.x + ty.z * nn.y + tz.z * nn.z);
+    if (STATS) cnt.nmap_hits++;
   }
   return hit.dist < PT_MAX_DIST;
 }
@@ -251,96 +347,150 @@ PT_DEV f3 env_lookup(const KParams& p, f3 dir)
   return top * (1.0f - b) + bot * b;
 }
 
-// ---------------------------------------------------------------- radiance (raytrace.cu:41-210)
+// ---------------------------------------------------------------- one path = one sample of one pixel
 
-template <int KIND, bool STATS>
-PT_DEV f3 radiance(const KParams& p, const float4* s_nodes, const float4* s_tris, f3 o, f3 d,
-                   Xorwow& rng, Counters& cnt)
+// Per-lane state of a path between two iterations of the reference's bounce loop
+// (raytrace.cu:67).  Holding it in a struct lets lanes of one wave sit at different bounce
+// depths, which is what the persistent kernel's refill relies on.
+struct Path {
+  f3 o, d, throughput, acc;
+  Xorwow rng;
+  float specular_col; // carried over between iterations
+  int b;
+  uint32_t x, y;
+};
+
+// kernel() prologue: seed, generateRay, camera_dof (raytrace.cu:227-240)
+PT_DEV void path_begin(const KParams& p, uint32_t x, uint32_t y, Path& st)
 {
-  f3 acc = mk3(0.0f);
-  f3 throughput = mk3(1.0f);
-  Hit inter; // value-initialised + carried over
+  // raytrace.cu:227-229 with the reference's launch geometry (16x16 blocks, padded grid)
+  const uint32_t grid_x = p.width / 16u + 1u;
+  const uint32_t tid = ((x >> 4) + (y >> 4) * grid_x) * 256u + (y & 15u) * 16u + (x & 15u);
+  xorwow_init(st.rng, p.hash_seed + tid);
+
+  // generateRay (intersection.cuh:75-97), pixel-invariant terms precomputed on the host
+  const int half_w = (int)(p.width / 2u), half_h = (int)(p.height / 2u);
+  const f3 screen_pos = (p.cam_p0 + (p.cam_u * (float)((int)x - half_w))) + (p.cam_v * (float)((int)y - half_h));
+  f3 dir = normalize(screen_pos - p.cam_pos);
+  f3 origin = p.cam_pos;
+
+  // camera_dof (post_process.cuh:49-67)
+  const f3 focal_point = p.focus_dist * dir;
+  const float random_angle = (float)((double)(xorwow_uniform(st.rng) * 2.0f) * 3.14159265358979323846);
+  const float random_radius = xorwow_uniform(st.rng) * p.aperture;
+  float sn, cs;
+  pt_sincosf(random_angle, sn, cs);
+  const f3 ap = (cs * p.cam_u + sn * p.cam_v) * random_radius;
+  st.d = normalize(focal_point - ap);
+  st.o = origin + ap;
+
+  st.throughput = mk3(1.0f);
+  st.acc = mk3(0.0f);
+  st.specular_col = 0.0f;
+  st.b = 0;
+  st.x = x;
+  st.y = y;
+}
+
+// One iteration of radiance()'s loop (raytrace.cu:67-207) is split around the nearest-hit search
+// so that the search can run in another lane (workgroup ray compaction):
+//   r1 = path_pre(st);  n = trace_nearest(st.o, st.d);  done = path_post(st, r1, n);
+// When the camera moved, the "iteration" is the whole preview sample (raytrace.cu:54-62).
+PT_DEV float path_pre(const KParams& p, Path& st)
+{
+  return p.is_static ? xorwow_uniform(st.rng) : 0.0f; // raytrace.cu:70: drawn before tracing
+}
+
+// Returns true when the path is complete (st.acc is final).
+template <bool STATS>
+PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Counters& cnt)
+{
+  Hit inter;
   inter.normal = mk3(0.f); inter.diffuse_col = mk3(0.f);
-  inter.dist = 0.f; inter.specular_col = 0.f; inter.ior = 0.f; inter.light = -1;
+  inter.dist = 0.f; inter.specular_col = st.specular_col; inter.ior = 0.f; inter.light = -1;
+  const bool found = resolve_hit<STATS>(p, st.d, nearest, inter, cnt);
 
-  if (!p.is_static) { // raytrace.cu:54-62
-    if (intersect<KIND, STATS>(p, s_nodes, s_tris, o, d, inter, cnt)) return inter.diffuse_col;
-    return env_lookup(p, d);
+  if (!p.is_static) {
+    st.acc = found ? inter.diffuse_col : env_lookup(p, st.d);
+    return true;
   }
 
-  bool missed = false;
   const int max_bounces = p.bounces;
-  for (int b = 0; b < max_bounces; b++) {
-    const float r1 = xorwow_uniform(rng);
-    bool found = false;
-    if (!missed) {
-      found = intersect<KIND, STATS>(p, s_nodes, s_tris, o, d, inter, cnt);
-      missed = !found;
-    } else if (STATS) {
-      cnt.rays++; // the reference issues this (futile) intersect() call; count it as a ray
+  st.specular_col = inter.specular_col;
+  if (!found) {
+    // The reference keeps looping with the unchanged ray (raytrace.cu:194-199): every remaining
+    // iteration misses again and adds the same environment sample.  Run them here, without
+    // the walk, drawing r1 exactly as the loop does.
+    const f3 env = env_lookup(p, st.d);
+    for (;;) {
+      st.acc = st.acc + env * st.throughput;
+      const float pmax = __builtin_fmaxf(st.throughput.x, __builtin_fmaxf(st.throughput.y, st.throughput.z));
+      if (r1 > pmax && st.b > 1) return true;
+      st.throughput = st.throughput * (1.0f / pmax);
+      if (++st.b >= max_bounces) return true;
+      r1 = xorwow_uniform(st.rng);
+      if (STATS) cnt.rays++; // the reference issues this (futile) intersect() call; count it as a ray
     }
-    if (found) {
-      const float cos_theta = dot(inter.normal, d);
-      f3 oriented_normal = inter.normal;
-      const f3 spec = normalize(reflect(d, inter.normal));
-      const f3 direct_light = inter.diffuse_col / 0.5f; // brdf_lambert / pdf_lambert (brdf.cuh:14-31)
-      if (inter.ior == 1.0f || inter.light >= 0) {
-        if (inter.light >= 0) {
-          const float4 la = p.lights[inter.light * 2 + 0], lb = p.lights[inter.light * 2 + 1];
-          acc = acc + (mk3(la.x, la.y, la.z) * lb.z) * throughput;
-        }
-        const float phi = (float)((double)2.0f * 3.14159265358979323846 * (double)xorwow_uniform(rng));
-        const float sin_t = __builtin_sqrtf(r1);
-        const float cos_t = __builtin_sqrtf(1.f - r1);
-        const f3 axis = ((double)__builtin_fabsf(oriented_normal.x) > .1) ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
-        const f3 u = normalize(cross(axis, oriented_normal));
-        const f3 v = cross(oriented_normal, u);
-        float sphi, cphi;
-        pt_sincosf(phi, sphi, cphi);
-        const f3 dd = normalize(v * sin_t * cphi + u * sphi * sin_t + oriented_normal * cos_t);
-        o = o + d * inter.dist;
-        d = mix(dd, spec, inter.specular_col);
-        o = o + d * 0.03f;
-        throughput = throughput * direct_light;
-      } else {
-        const float n1 = 1.0f;
-        const float n2 = inter.ior;
-        oriented_normal = cos_theta < 0 ? inter.normal : inter.normal * -1.0f;
-        const float c1 = dot(oriented_normal, d);
-        const bool entering = dot(inter.normal, oriented_normal) > 0;
-        const float eta = entering ? n1 / n2 : n2 / n1;
-        const float eta_2 = eta * eta;
-        const float c2_term = 1.0f - eta_2 * (1.0f - c1 * c1);
-        if (c2_term < 0.0f) {
-          o = o + oriented_normal * inter.dist / 100.f;
-          d = spec;
-        } else {
-          float R0 = (n2 - n1) / (n1 + n2);
-          R0 *= R0;
-          const float c2 = __builtin_sqrtf(c2_term);
-          const f3 T = normalize(eta * d + (eta * c1 - c2) * oriented_normal);
-          const float f_cos_theta = pt_powf(cos_theta, 5.0f);
-          const float f_r = R0 + (1.0f - R0) * f_cos_theta;
-          if (xorwow_uniform(rng) < 0.25f) {
-            throughput = throughput * (f_r * direct_light);
-            o = o + oriented_normal * inter.dist / 100.f;
-            d = spec;
-          } else {
-            const float f_t = 1.0f - f_r;
-            throughput = throughput * (f_t * direct_light);
-            o = o + oriented_normal * inter.dist / 10000.f;
-            d = T;
-          }
-        }
-      }
-    } else {
-      acc = acc + env_lookup(p, d) * throughput;
-    }
-    const float pmax = __builtin_fmaxf(throughput.x, __builtin_fmaxf(throughput.y, throughput.z));
-    if (r1 > pmax && b > 1) return acc;
-    throughput = throughput * (1.0f / pmax);
   }
-  return acc;
+
+  const f3 d = st.d;
+  const float cos_theta = dot(inter.normal, d);
+  f3 oriented_normal = inter.normal;
+  const f3 spec = normalize(reflect(d, inter.normal));
+  const f3 direct_light = inter.diffuse_col / 0.5f; // brdf_lambert / pdf_lambert (brdf.cuh:14-31)
+  if (inter.ior == 1.0f || inter.light >= 0) {
+    if (inter.light >= 0) {
+      const float4 la = p.lights[inter.light * 2 + 0], lb = p.lights[inter.light * 2 + 1];
+      st.acc = st.acc + (mk3(la.x, la.y, la.z) * lb.z) * st.throughput;
+    }
+    const float phi = (float)((double)2.0f * 3.14159265358979323846 * (double)xorwow_uniform(st.rng));
+    const float sin_t = __builtin_sqrtf(r1);
+    const float cos_t = __builtin_sqrtf(1.f - r1);
+    const f3 axis = (__builtin_fabsf(oriented_normal.x) >= 0.1f) /* == (double)|x| > .1: 0.1f is the first float above the double .1 */ ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+    const f3 u = normalize(cross(axis, oriented_normal));
+    const f3 v = cross(oriented_normal, u);
+    float sphi, cphi;
+    pt_sincosf(phi, sphi, cphi);
+    const f3 dd = normalize(v * sin_t * cphi + u * sphi * sin_t + oriented_normal * cos_t);
+    st.o = st.o + d * inter.dist;
+    st.d = mix(dd, spec, inter.specular_col);
+    st.o = st.o + st.d * 0.03f;
+    st.throughput = st.throughput * direct_light;
+  } else {
+    const float n1 = 1.0f;
+    const float n2 = inter.ior;
+    oriented_normal = cos_theta < 0 ? inter.normal : inter.normal * -1.0f;
+    const float c1 = dot(oriented_normal, d);
+    const bool entering = dot(inter.normal, oriented_normal) > 0;
+    const float eta = entering ? n1 / n2 : n2 / n1;
+    const float eta_2 = eta * eta;
+    const float c2_term = 1.0f - eta_2 * (1.0f - c1 * c1);
+    if (c2_term < 0.0f) {
+      st.o = st.o + oriented_normal * inter.dist / 100.f;
+      st.d = spec;
+    } else {
+      float R0 = (n2 - n1) / (n1 + n2);
+      R0 *= R0;
+      const float c2 = __builtin_sqrtf(c2_term);
+      const f3 T = normalize(eta * d + (eta * c1 - c2) * oriented_normal);
+      const float f_cos_theta = pt_powf(cos_theta, 5.0f);
+      const float f_r = R0 + (1.0f - R0) * f_cos_theta;
+      if (xorwow_uniform(st.rng) < 0.25f) {
+        st.throughput = st.throughput * (f_r * direct_light);
+        st.o = st.o + oriented_normal * inter.dist / 100.f;
+        st.d = spec;
+      } else {
+        const float f_t = 1.0f - f_r;
+        st.throughput = st.throughput * (f_t * direct_light);
+        st.o = st.o + oriented_normal * inter.dist / 10000.f;
+        st.d = T;
+      }
+    }
+  }
+  const float pmax = __builtin_fmaxf(st.throughput.x, __builtin_fmaxf(st.throughput.y, st.throughput.z));
+  if (r1 > pmax && st.b > 1) return true;
+  st.throughput = st.throughput * (1.0f / pmax);
+  return ++st.b >= max_bounces;
 }
 
 // ---------------------------------------------------------------- post process
@@ -383,15 +533,55 @@ PT_DEV void stage_to_lds(float4* dst, const float4* src, uint32_t n16)
   for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
 }
 
-// ---------------------------------------------------------------- the megakernel
-
-// Workgroup = 256 threads = 4 waves; wave w owns the 8x8 tile (w&1, w>>1) of a 16x16 block.
-template <int KIND, bool LDS_RESIDENT, bool STATS>
-__global__ void __launch_bounds__(256) pt_megakernel(const KParams p)
+// The unsplit form used when a lane traces its own ray.
+template <int KIND, bool STATS>
+PT_DEV bool path_step(const KParams& p, const float4* s_nodes, const float4* s_tris, Path& st, Counters& cnt)
 {
-  extern __shared__ float4 s_mem[];
-  const float4* s_nodes;
-  const float4* s_tris;
+  const float r1 = path_pre(p, st);
+  const Nearest n = trace_nearest<KIND, STATS>(p, s_nodes, s_tris, st.o, st.d, cnt);
+  return path_post<STATS>(p, st, r1, n, cnt);
+}
+
+// kernel() epilogue: clamp, temporal accumulation, tonemap, gamma, post-process, RGBA8 store
+// (raytrace.cu:248-270)
+PT_DEV void path_finish(const KParams& p, const Path& st)
+{
+  f3 rad = mk3(clamp01(st.acc.x), clamp01(st.acc.y), clamp01(st.acc.z));
+  const uint32_t x = st.x, y = st.y;
+  // row-flipped accumulator index (raytrace.cu:252)
+  const size_t i = (size_t)(p.height - y - 1u - p.tfb_row0) * p.width + x;
+  float* tp = p.tfb + i * 3;
+  f3 t = mk3(tp[0], tp[1], tp[2]);
+  t = t * (float)p.is_static;
+  t = t + rad;
+  tp[0] = t.x; tp[1] = t.y; tp[2] = t.z;
+  rad = t / p.frame_nb_f;
+  rad = exposure(rad);
+  const float g = 1.0f / 2.2f;
+  rad = mk3(pt_powf(rad.x, g), pt_powf(rad.y, g), pt_powf(rad.z, g));
+  rad = post_process(p.post_id, rad);
+  const uint32_t px = (pt_f2u(rad.x * 255.0f) & 0xffu) | ((pt_f2u(rad.y * 255.0f) & 0xffu) << 8) |
+                      ((pt_f2u(rad.z * 255.0f) & 0xffu) << 16);
+  p.surface[(size_t)(y - p.surf_row0) * p.width + x] = px;
+}
+
+template <bool STATS>
+PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t samples)
+{
+  if (!STATS) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long v[8] = { cnt.rays, cnt.nodes, cnt.tris, cnt.mesh_hits, cnt.nmap_hits, samples,
+                              cnt.wave_node_iters, cnt.wave_tri_iters };
+  for (int k = 0; k < 8; ++k) {
+    unsigned long long s = v[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0 && s) atomicAdd(&p.stats[k], s);
+  }
+}
+
+template <int KIND, bool LDS_RESIDENT>
+PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes, const float4*& s_tris)
+{
   if (LDS_RESIDENT) {
     if (KIND == 1) {
       stage_to_lds(s_mem, p.tris_brute, p.n_faces * 3);
@@ -408,69 +598,282 @@ __global__ void __launch_bounds__(256) pt_megakernel(const KParams p)
     s_nodes = p.nodes;
     s_tris = KIND == 1 ? p.tris_brute : p.tris_bvh;
   }
+}
+
+// ---------------------------------------------------------------- the megakernel, tile form
+
+// One thread per pixel, as in the reference.  Workgroup = 256 threads = 4 waves; wave w owns
+// the 8x8 tile (w&1, w>>1) of a 16x16 block.  Lanes whose path ended idle until the wave is done.
+template <int KIND, bool LDS_RESIDENT, bool STATS, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, PT_TILE_WAVES_PER_EU) pt_megakernel(const KParams p)
+{
+  extern __shared__ float4 s_mem[];
+  const float4* s_nodes;
+  const float4* s_tris;
+  stage_scene<KIND, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris);
 
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // BLOCK/64 waves as a 2 x (BLOCK/128) grid of 8x8 tiles: the block covers 16 x (BLOCK/16) pixels
   const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-  const uint32_t y = p.row_begin + blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+  const uint32_t y = p.row_begin + blockIdx.y * (BLOCK / 16u) + (wave >> 1) * 8u + (lane >> 3);
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = 0;
   const bool active = x < p.width && y < p.row_end;
-
   if (active) {
-    // raytrace.cu:227-229 with the reference's launch geometry (16x16 blocks, padded grid)
-    const uint32_t grid_x = p.width / 16u + 1u;
-    const uint32_t tid = ((x >> 4) + (y >> 4) * grid_x) * 256u + (y & 15u) * 16u + (x & 15u);
-    Xorwow rng;
-    xorwow_init(rng, p.hash_seed + tid);
+    Path st;
+    path_begin(p, x, y, st);
+    while (!path_step<KIND, STATS>(p, s_nodes, s_tris, st, cnt)) {}
+    path_finish(p, st);
+  }
+  flush_counters<STATS>(p, cnt, active ? 1u : 0u);
+}
 
-    // generateRay (intersection.cuh:75-97), pixel-invariant terms precomputed on the host
-    const int half_w = (int)(p.width / 2u), half_h = (int)(p.height / 2u);
-    const f3 screen_pos = (p.cam_p0 + (p.cam_u * (float)((int)x - half_w))) + (p.cam_v * (float)((int)y - half_h));
-    f3 dir = normalize(screen_pos - p.cam_pos);
-    f3 origin = p.cam_pos;
+// ---------------------------------------------------------------- the megakernel, persistent form
 
-    // camera_dof (post_process.cuh:49-67)
-    {
-      const f3 focal_point = p.focus_dist * dir;
-      const float random_angle = (float)((double)(xorwow_uniform(rng) * 2.0f) * 3.14159265358979323846);
-      const float random_radius = xorwow_uniform(rng) * p.aperture;
-      float sn, cs;
-      pt_sincosf(random_angle, sn, cs);
-      const f3 ap = (cs * p.cam_u + sn * p.cam_v) * random_radius;
-      dir = normalize(focal_point - ap);
-      origin = origin + ap;
+// Persistent waves with lane refill ("wavefront-level compaction/restart").  The grid is sized
+// to the machine, the scene is staged into LDS once per workgroup, and every wave64 pulls 8x8
+// pixel tiles from a global ticket counter.  A lane whose path has ended does not idle: once at
+// least p.refill_min lanes are idle (ballot + popcount), they write their pixels and take the next
+// pixels of the wave's tile queue (rank among idle lanes = mbcnt of the ballot), so the BVH walk
+// always runs with a nearly full exec mask and lanes at different bounce depths share it.
+template <int KIND, bool LDS_RESIDENT, bool STATS>
+__global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER_EU) pt_megakernel_persistent(const KParams p)
+{
+  extern __shared__ float4 s_mem[];
+  const float4* s_nodes;
+  const float4* s_tris;
+  stage_scene<KIND, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris);
+
+  const uint32_t lane = threadIdx.x & 63u;
+  Counters cnt;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = 0;
+  uint32_t samples = 0;
+
+  Path st;
+  st.o = st.d = st.throughput = st.acc = mk3(0.f);
+  st.rng.v0 = st.rng.v1 = st.rng.v2 = st.rng.v3 = st.rng.v4 = st.rng.d = 0;
+  st.specular_col = 0.f; st.b = 0; st.x = st.y = 0;
+  bool idle = true;        // this lane has no path in flight
+  bool has_output = false; // ... but holds a finished, not yet written sample
+  // wave-uniform tile queue.  A ticket is `tiles_per_ticket` consecutive 8x8 tiles; a wave's
+  // first ticket is its own global wave index (no atomic), later ones come from the shared
+  // counter, which starts at the number of waves.  One returning atomic per ~256+ pixels keeps
+  // the single counter far below its ~88 dequeues/us saturation point (MI355X_MICROARCH.md).
+  uint32_t tile_x0 = 0, tile_y0 = 0, qpos = 64;
+  uint32_t tile = 0, tile_end = 0; // tiles [tile, tile_end) of the current ticket remain
+  uint32_t ticket = blockIdx.x * (PT_PERSISTENT_THREADS / 64u) + (threadIdx.x >> 6);
+  bool have_ticket = true;         // `ticket` not yet expanded into tiles
+  bool exhausted = false;
+
+  for (;;) {
+    const unsigned long long idle_mask = __ballot(idle);
+    if ((uint32_t)__popcll(idle_mask) >= p.refill_min || idle_mask == ~0ull) {
+      if (idle && has_output) {
+        path_finish(p, st);
+        has_output = false;
+        if (STATS) samples++;
+      }
+      unsigned long long need = idle_mask;
+      while (need) {
+        if (qpos >= 64u) {
+          if (exhausted) break;
+          if (tile >= tile_end) {
+            if (!have_ticket) {
+              uint32_t t = 0;
+              if (lane == 0) t = atomicAdd(p.tile_counter, 1u);
+              ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            }
+            have_ticket = false;
+            tile = ticket * p.tiles_per_ticket;
+            if (tile >= p.n_tiles) { exhausted = true; break; }
+            tile_end = tile + p.tiles_per_ticket;
+            if (tile_end > p.n_tiles) tile_end = p.n_tiles;
+          }
+          tile_x0 = (tile % p.tiles_x) * 8u;
+          tile_y0 = p.row_begin + (tile / p.tiles_x) * 8u;
+          ++tile;
+          qpos = 0;
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+        const uint32_t avail = 64u - qpos;
+        if (idle && rank < avail) {
+          const uint32_t k = qpos + rank;
+          const uint32_t x = tile_x0 + (k & 7u), y = tile_y0 + (k >> 3);
+          if (x < p.width && y < p.row_end) {
+            path_begin(p, x, y, st);
+            idle = false;
+            has_output = true;
+          }
+        }
+        const uint32_t wanted = (uint32_t)__popcll(need);
+        qpos += wanted < avail ? wanted : avail;
+        need = __ballot(idle);
+      }
+    }
+    if (__ballot(!idle) == 0ull) break;
+    if (!idle) idle = path_step<KIND, STATS>(p, s_nodes, s_tris, st, cnt);
+  }
+  flush_counters<STATS>(p, cnt, samples);
+}
+
+// ---------------------------------------------------------------- the megakernel, blockwise form
+
+// Persistent WORKGROUPS with per-bounce ray compaction, octant sort and dynamic ray fetch.
+//
+// Measured on MI355X (DESIGN.md "Kernels"): lanes of a wave that trace incoherent bounce rays
+// spend most box-test iterations masked off — with every lane live the wave runs max(length) not
+// mean(length) iterations (38 % lane utilisation on bounce 1 of indoor), and paths that ended
+// leave holes (19 % / 12 % on bounces 2 / 3).  Refilling holes with NEW PATHS in the middle of
+// old ones (pt_megakernel_persistent) loses more to mixing coherent primary rays with incoherent
+// ones than it gains.  What this kernel does instead, per super-tile of PT_BW_THREADS pixels:
+//   * bounce 0 (coherent primary rays, 93 % utilisation) is traced in place;
+//   * before every later bounce the live rays are written to an LDS pool in (ray octant, wave,
+//     lane) order — a counting sort from 8 ballots per wave and one wave scan of the count table;
+//   * the waves drain the pool cooperatively: a lane whose walk has ended stores its 16-byte
+//     Nearest record and, once PT_BW_FETCH_MIN lanes of its wave are idle (ballot + popcount),
+//     they take the next rays from the pool head (one LDS atomic per wave, rank = mbcnt) — the
+//     wavefront-level restart keeps the box-test loop full with rays of the SAME bounce depth;
+//   * owners read their record back and shade; path state never leaves its lane.
+template <bool LDS_RESIDENT, bool STATS>
+__global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakernel_blockwise(const KParams p)
+{
+  constexpr uint32_t NW = PT_BW_THREADS / 64u; // waves per workgroup
+  constexpr uint32_t NE = NW * 8u;             // entries of the [octant][wave] count table
+  constexpr uint32_t EPL = (NE + 63u) / 64u;   // table entries scanned per lane (1 or 2)
+  static_assert(NW % 4u == 0 && NE <= 128u, "workgroup must be 4k waves, at most 16");
+  extern __shared__ float4 s_mem[];
+  const float4* s_nodes;
+  const float4* s_tris;
+  stage_scene<2, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris);
+  // behind the staged scene: ray pool (2 float4 per slot), count table, pool head, ticket
+  float4* pool = s_mem + (LDS_RESIDENT ? (p.n_nodes * 4u + p.n_faces * 3u) : 0u);
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(pool + PT_BW_THREADS * 2u);
+  uint32_t* s_head = s_cnt + 128;
+  uint32_t* s_ticket = s_cnt + 129;
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  Counters cnt;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = 0;
+  uint32_t samples = 0;
+  uint32_t ticket = blockIdx.x; // first super-tile is static, later ones come from the counter
+
+  for (;;) {
+    if (ticket >= p.n_tiles) break; // n_tiles counts super-tiles here (uniform across the block)
+    // super-tile = 4 x NW/4 tiles of 8x8 pixels; wave w owns tile (w & 3, w >> 2)
+    const uint32_t sx = (ticket % p.tiles_x) * 32u, sy = p.row_begin + (ticket / p.tiles_x) * (NW * 2u);
+    const uint32_t x = sx + (wave & 3u) * 8u + (lane & 7u);
+    const uint32_t y = sy + (wave >> 2) * 8u + (lane >> 3);
+    const bool active = x < p.width && y < p.row_end;
+    Path st;
+    bool live = active;
+    if (active) path_begin(p, x, y, st);
+    else { st.o = st.d = st.throughput = st.acc = mk3(0.f); st.b = 0; st.x = st.y = 0; st.specular_col = 0.f;
+           st.rng.v0 = st.rng.v1 = st.rng.v2 = st.rng.v3 = st.rng.v4 = st.rng.d = 0; }
+
+    // bounce 0: primary rays are coherent and all lanes are live — trace in place
+    if (live) live = !path_step<2, STATS>(p, s_nodes, s_tris, st, cnt);
+
+    for (;;) {
+      // ---- counting sort of the live rays by (octant, wave, lane)
+      const uint32_t oct = (st.d.x < 0.f ? 1u : 0u) | (st.d.y < 0.f ? 2u : 0u) | (st.d.z < 0.f ? 4u : 0u);
+      uint32_t rank = 0, my_count = 0;
+#pragma unroll
+      for (uint32_t o = 0; o < 8u; ++o) {
+        const unsigned long long m = __ballot(live && oct == o);
+        const uint32_t c = (uint32_t)__popcll(m);
+        if (oct == o) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (lane == o) my_count = c;
+      }
+      if (lane < 8u) s_cnt[lane * NW + wave] = my_count;
+      if (tid == 0) *s_head = 0u;
+      __syncthreads();
+      // every wave scans the table itself (no extra barrier): lane i owns entries [i*EPL, i*EPL+EPL)
+      uint32_t e0 = 0, e1 = 0;
+      if (lane * EPL < NE) e0 = s_cnt[lane * EPL];
+      if (EPL == 2u && lane * EPL + 1u < NE) e1 = s_cnt[lane * EPL + 1u];
+      uint32_t incl = e0 + e1;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += up;
+      }
+      const uint32_t n_live = __shfl(incl, 63, 64);
+      if (n_live == 0) break; // uniform: every wave computed the same total
+      const uint32_t excl = incl - (e0 + e1);
+      const uint32_t entry = oct * NW + wave;
+      uint32_t base = __shfl(excl, (int)(entry / EPL), 64);
+      if (EPL == 2u) { const uint32_t first = __shfl(e0, (int)(entry / EPL), 64); if (entry & 1u) base += first; }
+      const uint32_t slot = base + rank;
+      float r1 = 0.f;
+      if (live) {
+        r1 = path_pre(p, st);
+        pool[slot * 2u + 0u] = make_float4(st.d.x, st.d.y, st.d.z, st.o.x);
+        pool[slot * 2u + 1u] = make_float4(st.o.y, st.o.z, 0.f, 0.f);
+      }
+      __syncthreads();
+
+      // ---- cooperative drain of the pool with wave-level restart
+      {
+        Walk w;
+        w.node = PT_END; w.oct = 0; w.link_off = 8u;
+        w.o = w.d = w.inv = w.noi = mk3(0.f);
+        w.best.t = PT_MAX_DIST; w.best.u = w.best.v = 0.f; w.best.idx = PT_END;
+        bool have = false;        // this lane is walking ray `my_ray`
+        uint32_t my_ray = 0;
+        bool pool_empty = false;  // wave-uniform
+        for (;;) {
+          const unsigned long long idle_mask = __ballot(!have);
+          const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+          if (!pool_empty && (n_idle >= PT_BW_FETCH_MIN || idle_mask == ~0ull)) {
+            uint32_t head = 0;
+            if (lane == 0) head = atomicAdd(s_head, n_idle);
+            head = (uint32_t)__builtin_amdgcn_readfirstlane((int)head);
+            const uint32_t r = head + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+            if (!have && r < n_live) {
+              const float4 ra = pool[r * 2u + 0u], rb = pool[r * 2u + 1u];
+              walk_init(w, mk3(ra.w, rb.x, rb.y), mk3(ra.x, ra.y, ra.z), p.n_nodes);
+              have = true;
+              my_ray = r;
+              if (STATS) cnt.rays++;
+            }
+            if (head + n_idle >= n_live) pool_empty = true;
+          }
+          if (__ballot(have) == 0ull) break;
+          if (have) {
+            uint32_t leaf_first, leaf_count;
+            walk_to_leaf<STATS>(s_nodes, w, leaf_first, leaf_count, cnt.nodes, cnt.wave_node_iters);
+            if (leaf_count != 0u) {
+              walk_leaf<STATS>(s_tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters);
+            } else {
+              // walk over: publish the face-search result in the ray's own slot
+              pool[my_ray * 2u + 0u] = make_float4(w.best.t, w.best.u, w.best.v, u_as_f(w.best.idx));
+              have = false;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- owners pick up their record, run the light loop and shade
+      if (live) {
+        const float4 h = pool[slot * 2u + 0u];
+        Nearest n;
+        n.t = h.x; n.u = h.y; n.v = h.z; n.idx = f_as_u(h.w);
+        n = nearest_lights(p, st.o, st.d, n);
+        live = !path_post<STATS>(p, st, r1, n, cnt);
+      }
+      // the next iteration's table/head writes are ordered behind these reads by its barrier, and
+      // its ray writes come after that barrier, so the pool is free again by then
     }
 
-    f3 rad = radiance<KIND, STATS>(p, s_nodes, s_tris, origin, dir, rng, cnt);
-    rad = mk3(clamp01(rad.x), clamp01(rad.y), clamp01(rad.z));
-
-    // temporal accumulation (raytrace.cu:250-258), row-flipped index
-    const size_t i = (size_t)(p.height - y - 1u - p.tfb_row0) * p.width + x;
-    float* tp = p.tfb + i * 3;
-    f3 t = mk3(tp[0], tp[1], tp[2]);
-    t = t * (float)p.is_static;
-    t = t + rad;
-    tp[0] = t.x; tp[1] = t.y; tp[2] = t.z;
-    rad = t / p.frame_nb_f;
-
-    rad = exposure(rad);
-    const float g = 1.0f / 2.2f;
-    rad = mk3(pt_powf(rad.x, g), pt_powf(rad.y, g), pt_powf(rad.z, g));
-    rad = post_process(p.post_id, rad);
-    const uint32_t px = (pt_f2u(rad.x * 255.0f) & 0xffu) | ((pt_f2u(rad.y * 255.0f) & 0xffu) << 8) |
-                        ((pt_f2u(rad.z * 255.0f) & 0xffu) << 16);
-    p.surface[(size_t)(y - p.surf_row0) * p.width + x] = px;
+    if (active) { path_finish(p, st); if (STATS) samples++; }
+    // next super-tile
+    __syncthreads();
+    if (tid == 0) *s_ticket = atomicAdd(p.tile_counter, 1u);
+    __syncthreads();
+    ticket = *s_ticket;
   }
-
-  if (STATS) {
-    // wave reduction then one atomic per wave and counter
-    unsigned long long v[6] = { cnt.rays, cnt.nodes, cnt.tris, cnt.mesh_hits, cnt.nmap_hits, active ? 1ull : 0ull };
-    for (int k = 0; k < 6; ++k) {
-      unsigned long long s = v[k];
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-      if (lane == 0 && s) atomicAdd(&p.stats[k], s);
-    }
-  }
+  flush_counters<STATS>(p, cnt, samples);
 }
 
 // Nearest-hit query on explicit rays (tests: BVH vs brute force on the device).
@@ -481,26 +884,12 @@ __global__ void __launch_bounds__(256) pt_trace_rays_kernel(const KParams p, con
   if (i >= n) return;
   const f3 d = mk3(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
   const f3 o = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
-  Hit h;
-  h.normal = mk3(0.f); h.diffuse_col = mk3(0.f); h.dist = 0.f; h.specular_col = 0.f; h.ior = 0.f; h.light = -1;
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = 0;
-  Best best;
-  best.t = PT_MAX_DIST; best.u = 0.f; best.v = 0.f; best.idx = PT_END;
-  uint32_t a = 0, b = 0;
-  if (KIND == 1) traverse_brute<false>(p.tris_brute, p.n_faces, o, d, best, b);
-  else traverse_bvh<false>(p.nodes, p.tris_bvh, p.n_nodes, o, d, best, a, b);
-  int kind = best.idx != PT_END ? 1 : 0;
-  int index = kind ? (int)best.idx : -1;
-  float t = best.t;
-  for (uint32_t l = 0; l < p.n_lights; ++l) {
-    const float4 la = p.lights[l * 2 + 0], lb = p.lights[l * 2 + 1];
-    float ts;
-    if (intersect_sphere(o, d, mk3(la.w, lb.x, lb.y), lb.w, ts) && ts < t && ts >= 0.0f) {
-      kind = 2; index = (int)l; t = ts;
-    }
-  }
-  out[i] = make_int4(kind, index, (int)f_as_u(t), 0);
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = 0;
+  const Nearest nr = trace_nearest<KIND, false>(p, p.nodes, KIND == 1 ? p.tris_brute : p.tris_bvh, o, d, cnt);
+  const int kind = nr.idx == PT_END ? 0 : ((nr.idx & PT_LIGHT) ? 2 : 1);
+  const int index = kind == 0 ? -1 : (int)(nr.idx & ~PT_LIGHT);
+  out[i] = make_int4(kind, index, (int)f_as_u(nr.t), 0);
 }
 
 // ---------------------------------------------------------------- launchers
@@ -508,13 +897,13 @@ __global__ void __launch_bounds__(256) pt_trace_rays_kernel(const KParams p, con
 template <int KIND, bool LDS_RES, bool STATS>
 static hipError_t launch_variant(const KParams& p, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
-  auto kern = pt_megakernel<KIND, LDS_RES, STATS>;
+  auto kern = pt_megakernel<KIND, LDS_RES, STATS, PT_TILE_THREADS>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(PT_TILE_THREADS), lds_bytes, stream, p);
   return hipGetLastError();
 }
 
@@ -523,7 +912,8 @@ hipError_t launch_megakernel(const KParams& p, int kind, bool lds_resident, size
 {
   const uint32_t rows = p.row_end - p.row_begin;
   if (rows == 0 || p.width == 0) return hipSuccess;
-  dim3 grid((p.width + 15u) / 16u, (rows + 15u) / 16u);
+  const uint32_t block_rows = PT_TILE_THREADS / 16u;
+  dim3 grid((p.width + 15u) / 16u, (rows + block_rows - 1u) / block_rows);
   if (!lds_resident) lds_bytes = 0;
 #define PT_DISPATCH(K, L, S) return launch_variant<K, L, S>(p, grid, lds_bytes, stream)
   if (kind == 1) {
@@ -534,6 +924,86 @@ hipError_t launch_megakernel(const KParams& p, int kind, bool lds_resident, size
     else { if (stats) PT_DISPATCH(2, false, true); else PT_DISPATCH(2, false, false); }
   }
 #undef PT_DISPATCH
+}
+
+template <bool LDS_RES, bool STATS>
+static const void* persistent_entry()
+{
+  return reinterpret_cast<const void*>(pt_megakernel_persistent<2, LDS_RES, STATS>);
+}
+
+static const void* persistent_select(bool lds_resident, bool stats)
+{
+  if (lds_resident) return stats ? persistent_entry<true, true>() : persistent_entry<true, false>();
+  return stats ? persistent_entry<false, true>() : persistent_entry<false, false>();
+}
+
+// Resident workgroups per CU of the persistent variant (sizes its grid).
+hipError_t persistent_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out)
+{
+  if (!lds_resident) lds_bytes = 0;
+  const void* fn = persistent_select(lds_resident, false);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, PT_PERSISTENT_THREADS, lds_bytes);
+}
+
+hipError_t launch_megakernel_persistent(const KParams& p, bool lds_resident, size_t lds_bytes, bool stats,
+                                        uint32_t n_blocks, hipStream_t stream)
+{
+  if (p.n_tiles == 0 || n_blocks == 0) return hipSuccess;
+  if (!lds_resident) lds_bytes = 0;
+  const void* fn = persistent_select(lds_resident, stats);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  KParams pc = p;
+  void* args[] = { &pc };
+  return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_PERSISTENT_THREADS), args, lds_bytes, stream);
+}
+
+static const void* blockwise_select(bool lds_resident, bool stats)
+{
+  if (lds_resident)
+    return stats ? reinterpret_cast<const void*>(pt_megakernel_blockwise<true, true>)
+                 : reinterpret_cast<const void*>(pt_megakernel_blockwise<true, false>);
+  return stats ? reinterpret_cast<const void*>(pt_megakernel_blockwise<false, true>)
+               : reinterpret_cast<const void*>(pt_megakernel_blockwise<false, false>);
+}
+
+// LDS of the blockwise variant = staged scene (when resident) + exchange area + count table + ticket
+size_t blockwise_lds_bytes(bool lds_resident, size_t scene_lds_bytes)
+{
+  return (lds_resident ? scene_lds_bytes : 0) + (size_t)PT_BW_THREADS * 32u + 128u * 4u + 16u;
+}
+
+hipError_t blockwise_blocks_per_cu(bool lds_resident, size_t scene_lds_bytes, int* out)
+{
+  const size_t lds = blockwise_lds_bytes(lds_resident, scene_lds_bytes);
+  const void* fn = blockwise_select(lds_resident, false);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, PT_BW_THREADS, lds);
+}
+
+hipError_t launch_megakernel_blockwise(const KParams& p, bool lds_resident, size_t scene_lds_bytes, bool stats,
+                                       uint32_t n_blocks, hipStream_t stream)
+{
+  if (p.n_tiles == 0 || n_blocks == 0) return hipSuccess;
+  const size_t lds = blockwise_lds_bytes(lds_resident, scene_lds_bytes);
+  const void* fn = blockwise_select(lds_resident, stats);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  KParams pc = p;
+  void* args[] = { &pc };
+  return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_BW_THREADS), args, lds, stream);
 }
 
 hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,

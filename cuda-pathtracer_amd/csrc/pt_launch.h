@@ -11,6 +11,12 @@ struct KParams;
 // kind: 1 brute force, 2 BVH.  lds_bytes: dynamic LDS needed when lds_resident.
 hipError_t launch_megakernel(const KParams& p, int kind, bool lds_resident, size_t lds_bytes, bool stats,
                              hipStream_t stream);
+hipError_t persistent_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out);
+hipError_t launch_megakernel_persistent(const KParams& p, bool lds_resident, size_t lds_bytes, bool stats,
+                                        uint32_t n_blocks, hipStream_t stream);
+hipError_t blockwise_blocks_per_cu(bool lds_resident, size_t scene_lds_bytes, int* out);
+hipError_t launch_megakernel_blockwise(const KParams& p, bool lds_resident, size_t scene_lds_bytes, bool stats,
+                                       uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,
                              hipStream_t stream);
 

@@ -12,6 +12,7 @@
 #include "pt_launch.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -52,6 +53,15 @@ struct ptamd_context {
   std::vector<ptamd::DeviceCubemap> cubemaps;
   uint32_t frame_counter = 0; // raytrace.cu:296 `static unsigned int seed`
   unsigned long long* d_stats = nullptr;
+  // persistent variant: ring of tile ticket counters (one per in-flight launch) and grid sizing
+  uint32_t* d_tickets = nullptr;
+  uint32_t ticket_next = 0;
+  int n_cus = 0;
+  int blocks_per_cu[2] = { -1, -1 }; // [lds_resident]
+  int bw_blocks_per_cu[2] = { -1, -1 };
+  uint32_t default_kernel = PTAMD_KERNEL_BVH_PERSISTENT; // what PTAMD_KERNEL_AUTO means
+  uint32_t refill_min = 64;
+  uint32_t tiles_per_ticket = 1;
 };
 
 namespace ptamd {
@@ -60,6 +70,14 @@ namespace {
 constexpr size_t kLdsBudget = 64 * 1024;
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
 constexpr uint32_t kMaxLeaf = 4;
+constexpr uint32_t kTicketRing = 1024;
+#ifndef PT_PERSISTENT_THREADS
+#define PT_PERSISTENT_THREADS 512
+#endif
+#ifndef PT_BW_THREADS
+#define PT_BW_THREADS 512
+#endif
+constexpr uint32_t kPersistentThreads = PT_PERSISTENT_THREADS; // same macro as pt_kernels.hip
 
 int hip_fail(const char* what, hipError_t e)
 {
@@ -86,8 +104,8 @@ int upload(T*& dst, const void* src, size_t bytes)
 
 void free_scene(DeviceScene& s)
 {
-  hipFree(s.nodes); hipFree(s.tris_bvh); hipFree(s.tris_brute); hipFree(s.shade);
-  hipFree(s.materials); hipFree(s.lights); hipFree(s.textures); hipFree(s.texels);
+  void* ptrs[] = { s.nodes, s.tris_bvh, s.tris_brute, s.shade, s.materials, s.lights, s.textures, s.texels };
+  for (void* q : ptrs) (void)hipFree(q);
   s = DeviceScene();
 }
 
@@ -117,7 +135,7 @@ int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
   if (l->row_begin > l->row_end || l->row_end > l->height) { set_error("ptamd_raytrace: bad row band"); return PTAMD_ERR_ARG; }
   if (l->frame_nb == 0) { set_error("ptamd_raytrace: frame_nb must be >= 1"); return PTAMD_ERR_ARG; }
   if (l->bounces == 0 || l->bounces > 1024) { set_error("ptamd_raytrace: bounces out of range (1..1024)"); return PTAMD_ERR_ARG; }
-  if (l->kernel > PTAMD_KERNEL_BVH) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
+  if (l->kernel > PTAMD_KERNEL_BVH_BLOCKWISE) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
   return PTAMD_OK;
 }
 
@@ -166,7 +184,51 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   int kind = l->kernel == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2;
   const size_t lds = kind == 1 ? s.info.lds_bytes_brute : s.info.lds_bytes_bvh;
   const bool resident = lds <= kLdsBudget;
-  hipError_t e = launch_megakernel(p, kind, resident, lds, stats, static_cast<hipStream_t>(l->stream));
+  hipStream_t stream = static_cast<hipStream_t>(l->stream);
+  hipError_t e;
+  const uint32_t which = l->kernel == PTAMD_KERNEL_AUTO ? ctx->default_kernel : l->kernel;
+  if (which == PTAMD_KERNEL_BVH_BLOCKWISE) {
+    // persistent workgroups over 32x16 super-tiles; tickets 0..n_blocks-1 are static
+    const uint32_t rows = l->row_end - l->row_begin;
+    const uint32_t st_rows = (PT_BW_THREADS / 64u) * 2u; // super-tile = 32 x (2 * waves) pixels
+    p.tiles_x = (l->width + 31u) / 32u;
+    p.n_tiles = p.tiles_x * ((rows + st_rows - 1u) / st_rows);
+    if (p.n_tiles == 0) return PTAMD_OK;
+    int& bpc = ctx->bw_blocks_per_cu[resident ? 1 : 0];
+    if (bpc < 0) {
+      e = blockwise_blocks_per_cu(resident, lds, &bpc);
+      if (e != hipSuccess || bpc < 1) { bpc = -1; return hip_fail("occupancy query of the blockwise kernel", e); }
+    }
+    uint32_t n_blocks = (uint32_t)ctx->n_cus * (uint32_t)bpc;
+    if (n_blocks > p.n_tiles) n_blocks = p.n_tiles;
+    p.tile_counter = ctx->d_tickets + (ctx->ticket_next++ % kTicketRing);
+    PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)n_blocks, 1, stream));
+    e = launch_megakernel_blockwise(p, resident, lds, stats, n_blocks, stream);
+  } else if (which == PTAMD_KERNEL_BVH_PERSISTENT) {
+
+    const uint32_t rows = l->row_end - l->row_begin;
+    p.tiles_x = (l->width + 7u) / 8u;
+    p.n_tiles = p.tiles_x * ((rows + 7u) / 8u);
+    if (p.n_tiles == 0) return PTAMD_OK;
+    int& bpc = ctx->blocks_per_cu[resident ? 1 : 0];
+    if (bpc < 0) {
+      e = persistent_blocks_per_cu(resident, lds, &bpc);
+      if (e != hipSuccess || bpc < 1) { bpc = -1; return hip_fail("occupancy query of the persistent kernel", e); }
+    }
+    const uint32_t waves_per_block = kPersistentThreads / 64u;
+    uint32_t n_blocks = (uint32_t)ctx->n_cus * (uint32_t)bpc;
+    const uint32_t n_tickets = (p.n_tiles + ctx->tiles_per_ticket - 1u) / ctx->tiles_per_ticket;
+    const uint32_t useful = (n_tickets + waves_per_block - 1u) / waves_per_block;
+    if (n_blocks > useful) n_blocks = useful;
+    p.refill_min = ctx->refill_min;
+    p.tiles_per_ticket = ctx->tiles_per_ticket;
+    // tickets 0..n_waves-1 are taken statically by the waves; the shared counter hands out the rest
+    p.tile_counter = ctx->d_tickets + (ctx->ticket_next++ % kTicketRing);
+    PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)(n_blocks * waves_per_block), 1, stream));
+    e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
+  } else {
+    e = launch_megakernel(p, kind, resident, lds, stats, stream);
+  }
   if (e != hipSuccess) return hip_fail("megakernel launch", e);
   return PTAMD_OK;
 }
@@ -208,6 +270,22 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   if (!ctx) { set_error("ptamd_create: out of memory"); return PTAMD_ERR_ARG; }
   ctx->device = device_ordinal;
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), 8 * sizeof(unsigned long long)));
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), kTicketRing * sizeof(uint32_t)));
+  hipDeviceProp_t prop;
+  PT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+  ctx->n_cus = prop.multiProcessorCount;
+  if (const char* e = std::getenv("PTAMD_REFILL_MIN")) { // tuning knob
+    int v = std::atoi(e);
+    ctx->refill_min = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+  }
+  if (const char* e = std::getenv("PTAMD_DEFAULT_KERNEL")) { // tuning knob: 1..4
+    int v = std::atoi(e);
+    if (v >= 1 && v <= 4) ctx->default_kernel = (uint32_t)v;
+  }
+  if (const char* e = std::getenv("PTAMD_TILES_PER_TICKET")) {
+    int v = std::atoi(e);
+    ctx->tiles_per_ticket = (uint32_t)(v < 1 ? 1 : (v > 1024 ? 1024 : v));
+  }
   *out = ctx.release();
   return PTAMD_OK;
 }
@@ -215,10 +293,11 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
 void ptamd_destroy(ptamd_context* ctx)
 {
   if (!ctx) return;
-  hipSetDevice(ctx->device);
+  (void)hipSetDevice(ctx->device);
   for (auto& s : ctx->scenes) free_scene(s);
-  for (auto& c : ctx->cubemaps) hipFree(c.faces);
-  hipFree(ctx->d_stats);
+  for (auto& c : ctx->cubemaps) (void)hipFree(c.faces);
+  (void)hipFree(ctx->d_stats);
+  (void)hipFree(ctx->d_tickets);
   delete ctx;
 }
 
@@ -370,6 +449,7 @@ int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_t
   PT_HIP(hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
   out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
   out->mesh_hits = h[3]; out->nmap_hits = h[4]; out->samples = h[5];
+  out->wave_node_iters = h[6]; out->wave_tri_iters = h[7];
   return PTAMD_OK;
 }
 
@@ -398,15 +478,15 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   int4* d_out = nullptr;
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 16);
-  if (e != hipSuccess) { hipFree(d_rays); return hip_fail("hipMalloc", e); }
+  if (e != hipSuccess) { (void)hipFree(d_rays); return hip_fail("hipMalloc", e); }
   int rc = PTAMD_OK;
   if ((e = hipMemcpy(d_rays, rays_host, (size_t)n * 24, hipMemcpyHostToDevice)) != hipSuccess ||
       (e = launch_trace_rays(p, kernel == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2, d_rays, n, d_out, nullptr)) != hipSuccess ||
       (e = hipDeviceSynchronize()) != hipSuccess ||
       (e = hipMemcpy(out_host, d_out, (size_t)n * 16, hipMemcpyDeviceToHost)) != hipSuccess)
     rc = hip_fail("ptamd_trace_rays", e);
-  hipFree(d_rays);
-  hipFree(d_out);
+  (void)hipFree(d_rays);
+  (void)hipFree(d_out);
   return rc;
 }
 

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -50,7 +51,7 @@ struct BuildNode {
 };
 
 constexpr float kTravCost = 1.0f;
-constexpr float kIsectCost = 1.6f;
+float g_isect_cost = 1.6f; // SAH cost of one triangle test relative to one box test (build_bvh may override)
 constexpr int kBins = 32;
 
 struct Builder {
@@ -101,7 +102,7 @@ struct Builder {
         acc.reset();
         for (uint32_t i = 1; i < count; ++i) {
           acc.grow(prims[first + i - 1].box);
-          float cost = kTravCost + kIsectCost * inv_area * (acc.half_area() * (float)i + right_area[i] * (float)(count - i));
+          float cost = kTravCost + g_isect_cost * inv_area * (acc.half_area() * (float)i + right_area[i] * (float)(count - i));
           if (cost < best_cost) { best_cost = cost; best_axis = a; best_mid = i; best_binned = false; }
         }
       }
@@ -132,7 +133,7 @@ struct Builder {
         for (int b = 1; b < kBins; ++b) {
           acc.grow(bbox[b - 1]); n += bcnt[b - 1];
           if (n == 0 || rcnt[b] == 0) continue;
-          float cost = kTravCost + kIsectCost * inv_area * (acc.half_area() * (float)n + rarea[b] * (float)rcnt[b]);
+          float cost = kTravCost + g_isect_cost * inv_area * (acc.half_area() * (float)n + rarea[b] * (float)rcnt[b]);
           if (cost < best_cost) {
             best_cost = cost; best_axis = a; best_binned = true;
             best_plane = cbox.lo[a] + (float)b / scale;
@@ -141,7 +142,7 @@ struct Builder {
       }
     }
 
-    const float leaf_cost = kIsectCost * (float)count;
+    const float leaf_cost = g_isect_cost * (float)count;
     if (count <= max_leaf && (best_axis < 0 || leaf_cost <= best_cost)) return id; // leaf
 
     uint32_t mid;
@@ -187,6 +188,8 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   out = Bvh();
   if (n_faces == 0) return PTAMD_OK;
   if (n_faces >= (1u << 24)) { set_error("build_bvh: more than 2^24 faces"); return PTAMD_ERR_LIMIT; }
+  if (const char* e = std::getenv("PTAMD_BVH_MAX_LEAF")) max_leaf = (uint32_t)std::atoi(e);   // tuning knobs
+  if (const char* e = std::getenv("PTAMD_BVH_ISECT_COST")) g_isect_cost = (float)std::atof(e);
   if (max_leaf < 1) max_leaf = 1;
   if (max_leaf > 15) max_leaf = 15;
   Builder b;
@@ -302,19 +305,27 @@ void bvh_trace_host(const Bvh& bvh, const ptamd_face* faces, const float dir[3],
   float best_t = MAX_DIST, best_u = 0.f, best_v = 0.f;
   uint32_t best_idx = 0xFFFFFFFFu;
   const int oct = (dir[0] < 0.f ? 1 : 0) | (dir[1] < 0.f ? 2 : 0) | (dir[2] < 0.f ? 4 : 0);
-  const float inv[3] = { 1.0f / dir[0], 1.0f / dir[1], 1.0f / dir[2] };
+  // same slab formulation as the kernel (fma of lo/hi with 1/d and -o/d; zero components replaced
+  // by a tiny stand-in).  The device uses v_rcp_f32 (1 ulp) where this uses an exact division;
+  // the visited set may differ by a node, the result may not (conservative boxes).
+  float inv[3], noi[3];
+  for (int a = 0; a < 3; ++a) {
+    const float da = std::fabs(dir[a]) < 1e-30f ? std::copysign(1e-30f, dir[a]) : dir[a];
+    inv[a] = 1.0f / da;
+    noi[a] = -(origin[a] * inv[a]);
+  }
   uint32_t node = bvh.n_nodes ? 0u : 0xFFFFFFFFu;
   while (node != 0xFFFFFFFFu) {
     const float* q = &bvh.nodes[(size_t)node * 16];
     if (nodes_visited) ++*nodes_visited;
     float tnear = -std::numeric_limits<float>::infinity(), tfar = std::numeric_limits<float>::infinity();
     for (int a = 0; a < 3; ++a) {
-      float t0 = (q[a] - origin[a]) * inv[a];
-      float t1 = (q[4 + a] - origin[a]) * inv[a];
+      float t0 = std::fma(q[a], inv[a], noi[a]);
+      float t1 = std::fma(q[4 + a], inv[a], noi[a]);
       tnear = std::fmax(tnear, std::fmin(t0, t1));
       tfar = std::fmin(tfar, std::fmax(t0, t1));
     }
-    const bool hit = tnear <= tfar * 1.0000005f && tfar >= 0.0f && tnear <= best_t;
+    const bool hit = tnear <= tfar && tfar >= 0.0f && tnear <= best_t;
     const uint32_t info = f2u(q[3]);
     const uint32_t miss = f2u(q[8 + oct]);
     if (!hit) { node = miss; continue; }
@@ -335,7 +346,7 @@ void bvh_trace_host(const Bvh& bvh, const ptamd_face* faces, const float dir[3],
       const float py = dir[2] * e2x - dir[0] * e2z;
       const float pz = dir[0] * e2y - dir[1] * e2x;
       const float det = e1x * px + e1y * py + e1z * pz;
-      if ((double)det < 0.0000001) continue;
+      if (det < 1e-7f) continue; // == (double)det < 0.0000001 (intersection.cuh:110), see mt_test
       const float inv_det = 1.0f / det;
       const float tx = origin[0] - t[0], ty = origin[1] - t[1], tz = origin[2] - t[2];
       const float u = (tx * px + ty * py + tz * pz) * inv_det;

@@ -22,7 +22,7 @@ class PtamdError(RuntimeError):
 
 
 PTAMD_OK, PTAMD_ERR_ARG, PTAMD_ERR_HIP, PTAMD_ERR_IO, PTAMD_ERR_LIMIT = 0, 1, 2, 3, 4
-KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH = 0, 1, 2
+KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, KERNEL_BVH_PERSISTENT, KERNEL_BVH_BLOCKWISE = 0, 1, 2, 3, 4
 
 
 class Float3(C.Structure):
@@ -74,7 +74,8 @@ class Launch(C.Structure):
 
 class TraceStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
-                ("mesh_hits", C.c_uint64), ("nmap_hits", C.c_uint64), ("samples", C.c_uint64)]
+                ("mesh_hits", C.c_uint64), ("nmap_hits", C.c_uint64), ("samples", C.c_uint64),
+                ("wave_node_iters", C.c_uint64), ("wave_tri_iters", C.c_uint64)]
 
 
 class SceneInfo(C.Structure):

@@ -164,9 +164,11 @@ int ptamd_raytrace(ptamd_context* ctx, void* surface_rgba8, uint32_t scene_id, u
                    float* temporal_framebuffer, int32_t moved, uint32_t post_id);
 
 typedef enum {
-  PTAMD_KERNEL_AUTO = 0,        /* BVH traversal (the shipped default) */
-  PTAMD_KERNEL_BRUTE_FORCE = 1, /* the reference algorithm: every face, LDS-staged, wave-uniform */
-  PTAMD_KERNEL_BVH = 2          /* stackless threaded BVH, LDS-staged nodes + triangles */
+  PTAMD_KERNEL_AUTO = 0,          /* the shipped default: PTAMD_KERNEL_BVH_PERSISTENT */
+  PTAMD_KERNEL_BRUTE_FORCE = 1,   /* the reference algorithm: every face, LDS-staged, wave-uniform; 1 thread = 1 pixel */
+  PTAMD_KERNEL_BVH = 2,           /* stackless ordered BVH walk, LDS-staged nodes + triangles; 1 thread = 1 pixel */
+  PTAMD_KERNEL_BVH_PERSISTENT = 3, /* same walk in persistent waves with mid-path lane refill (ballot + mbcnt) */
+  PTAMD_KERNEL_BVH_BLOCKWISE = 4  /* persistent workgroups; live rays of each bounce compacted + octant-sorted through LDS */
 } ptamd_kernel_kind;
 
 /* Explicit form used by the bench, the tests and the multi-GPU row split. */
@@ -199,6 +201,8 @@ typedef struct {
   uint64_t mesh_hits;       /* intersect() calls won by a mesh face (one 16 B texel fetch each) */
   uint64_t nmap_hits;       /* of those, on normal-mapped materials (one 12 B fetch each) */
   uint64_t samples;         /* pixels rendered */
+  uint64_t wave_node_iters; /* wave-level executions of the box-test loop body (lane utilisation = nodes_visited / (64 * this)) */
+  uint64_t wave_tri_iters;  /* wave-level executions of the triangle-test loop body */
 } ptamd_trace_stats;
 
 /* Renders like ptamd_raytrace_ex with an instrumented build of the selected kernel and

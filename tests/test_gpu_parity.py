@@ -39,11 +39,12 @@ def assert_same(acc, rgba, ref_acc, ref_rgba, what=""):
     np.testing.assert_array_equal(rgba, ref_rgba, err_msg=what)
 
 
-KERNELS = ["bvh", "brute"]
+KERNELS = ["blockwise", "persistent", "bvh", "brute"]
 
 
 def kid(P, name):
-    return P.KERNEL_BVH if name == "bvh" else P.KERNEL_BRUTE_FORCE
+    return {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
+            "blockwise": P.KERNEL_BVH_BLOCKWISE}[name]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -88,7 +89,7 @@ def test_all_post_processes_and_deep_bounces(P, O, gpu_ctx):
     osc, ocam = O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera)
     for post in (0, 1, 2, 3):
         ref = O.render(osc, ocam, 48, 32, spp=2, bounces=8, post_id=post)
-        acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 8, P.KERNEL_BVH, post_id=post)
+        acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 8, P.KERNEL_AUTO, post_id=post)
         assert_same(acc, rgba, *ref, f"post {post}")
 
 
@@ -154,10 +155,13 @@ def test_row_band_split_is_bit_identical(P, gpu_ctx, indoor):
     ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
     W, H, spp, B = 200, 121, 2, 4
     full_acc, full_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
+    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE):
+        pa, pr = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, k, ids=ids)
+        assert_same(pa, pr, full_acc, full_rgba, f"kernel {k} vs tile kernel")
     for world in (2, 3, 8):
         accs, rgbas = [], []
         for rows in P.row_bands(H, world):
-            a, r = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, rows=rows, band_local=True, ids=ids)
+            a, r = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_AUTO, rows=rows, band_local=True, ids=ids)
             assert a.shape[0] == rows[1] - rows[0]
             accs.append(a)
             rgbas.append(r)
@@ -204,8 +208,9 @@ def test_large_scene_uses_global_memory_variant(P, O, gpu_ctx):
     info = gpu_ctx.scene_info(sid)
     assert info["lds_bytes_bvh"] > 64 * 1024
     ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 48, 32, spp=2, bounces=3)
-    acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 3, P.KERNEL_BVH)
-    assert_same(acc, rgba, *ref, "global-memory BVH")
+    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE):
+        acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 3, k)
+        assert_same(acc, rgba, *ref, f"global-memory BVH kernel {k}")
 
 
 def test_full_size_properties_1080p_4spp_4bounces(P, O, gpu_ctx, indoor):
@@ -214,18 +219,22 @@ def test_full_size_properties_1080p_4spp_4bounces(P, O, gpu_ctx, indoor):
     cube = P.cubemap_for_scene(indoor)
     ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
     W, H, spp, B = 1920, 1080, 4, 4
-    bvh_acc, bvh_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
+    bvh_acc, bvh_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_AUTO, ids=ids)
+    # (0) persistent waves with lane refill == one-thread-per-pixel walk
+    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE):
+        t_acc, t_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, k, ids=ids)
+        assert_same(bvh_acc, bvh_rgba, t_acc, t_rgba, f"1080p default kernel vs kernel {k}")
     # (1) the BVH walk returns the brute-force loop's result for every ray of every path
     bf_acc, bf_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BRUTE_FORCE, ids=ids)
     assert_same(bvh_acc, bvh_rgba, bf_acc, bf_rgba, "1080p BVH vs brute force")
     # (2) N spp == sum of N one-spp launches
-    parts = [gpu_render(P, gpu_ctx, indoor, cube, W, H, 1, B, P.KERNEL_BVH, first_frame=k, ids=ids)[0] for k in (1, 2, 3, 4)]
+    parts = [gpu_render(P, gpu_ctx, indoor, cube, W, H, 1, B, P.KERNEL_AUTO, first_frame=k, ids=ids)[0] for k in (1, 2, 3, 4)]
     np.testing.assert_array_equal(bvh_acc, ((parts[0] + parts[1]) + parts[2]) + parts[3])
     # (3) idempotence: rendering again gives the same bits
-    again = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
+    again = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_AUTO, ids=ids)
     assert_same(*again, bvh_acc, bvh_rgba, "re-render")
     # (4) 8-way row split == full frame
-    rg = np.concatenate([gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, rows=r, band_local=True, ids=ids)[1]
+    rg = np.concatenate([gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_AUTO, rows=r, band_local=True, ids=ids)[1]
                          for r in P.row_bands(H, 8)], axis=0)
     np.testing.assert_array_equal(rg, bvh_rgba)
     # (5) oracle on full-resolution rows (a crop the CPU finishes in seconds)
@@ -249,6 +258,13 @@ def test_stats_are_consistent(P, O, gpu_ctx, indoor):
     l = gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), W, H, frame_nb=1, bounces=4, kernel=P.KERNEL_BVH)
     s_bvh = gpu_ctx.raytrace_stats(l)
     fr.reset()
+    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE):
+        fr.reset()
+        l.kernel = k
+        s_k = gpu_ctx.raytrace_stats(l)
+        for key in ("rays", "nodes_visited", "tris_tested", "mesh_hits", "nmap_hits", "samples"):
+            assert s_k[key] == s_bvh[key]                  # scheduling changes, the work does not
+    fr.reset()
     l.kernel = P.KERNEL_BRUTE_FORCE
     s_bf = gpu_ctx.raytrace_stats(l)
     O.render(O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera), W, H, spp=1, bounces=4)
@@ -269,7 +285,7 @@ def test_error_behaviour(P, gpu_ctx, indoor):
         base = dict(frame_nb=1, bounces=3)
         base.update(kw)
         return gpu_ctx.make_launch(fr.surface, fr.accum, ids[0], ids[1], indoor.camera_struct(), 32, 32, **base)
-    for bad in (dict(frame_nb=0), dict(bounces=0), dict(post_id=4), dict(rows=(5, 40)), dict(rows=(9, 3)), dict(kernel=7)):
+    for bad in (dict(frame_nb=0), dict(bounces=0), dict(post_id=4), dict(rows=(5, 40)), dict(rows=(9, 3)), dict(kernel=9)):
         with pytest.raises(P.PtamdError) as e:
             gpu_ctx.raytrace_ex(launch(**bad))
         assert e.value.status == P.native.PTAMD_ERR_ARG
