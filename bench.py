@@ -49,6 +49,40 @@ def parse_args():
     return ap.parse_args()
 
 
+class _StdoutToStderr:
+    """Routes fd 1 to fd 2 while active: RCCL prints a version banner to stdout on first use, and
+    stdout must carry exactly one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask and cgroup CPU quota (the GPU box exposes
+    every host core but grants a share of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(hs, cube, width, height, bounces, target_seconds):
     """The oracle (a port of the reference algorithm: brute force over every face) on all host
     cores, on a bounded sample of the SAME workload: whole-frame 1-spp launches (seeds 1, 2, ..)
@@ -56,7 +90,7 @@ def cpu_baseline(hs, cube, width, height, bounces, target_seconds):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import pt_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     osc = O.OracleScene.from_host_scene(hs, cube)
     ocam = O.camera_from_record(hs.camera)
     # rows sample sized from a quick probe so that slow hosts stay bounded
@@ -98,9 +132,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_gather = os.environ.get("PTAMD_BENCH_FORCE_GATHER") == "1"  # exercise the collective at N = 1
+    if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
     kernel = {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
@@ -114,7 +151,7 @@ def main():
     info = ctx.scene_info(sid)
 
     dev = torch.device("cuda", local_rank)
-    bg = P.BandGather(H, W, world, rank, dev) if world > 1 else None
+    bg = P.BandGather(H, W, world, rank, dev) if (world > 1 or force_gather) else None
     y0, y1 = P.row_bands(H, world)[rank]
     fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True)
     stream = torch.cuda.current_stream()
@@ -129,7 +166,7 @@ def main():
         fr.render(spp=spp, bounces=B, kernel=kernel, stream=stream)
         if i_timed is not None:
             ev1[i_timed].record(stream)
-        if world > 1:
+        if bg is not None:
             bg.gather(fr.surface)  # one RCCL all-gather of the RGBA8 bands per frame
 
     def barrier():
@@ -137,9 +174,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    with _StdoutToStderr():  # first collective = communicator setup (and RCCL's banner)
+        for _ in range(args.warmup):
+            step()
+        barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -215,7 +253,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cube, W, H, B, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if bg is not None and rank == 0:
+        # the gathered frame must equal rank 0's own band in its rows (cheap self-check of the collective)
+        frame = bg.assemble()
+        assert torch.equal(frame[y0:y1], fr.surface), "gathered frame does not contain rank 0's band"
+    if world > 1 or force_gather:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,4 +15,5 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel $KERNEL > $OUT/pass$i.log 2>&1
   echo "pass $i ($SET) rc=$?"
 done
-python3 $R/scripts/summarize_pmc.py $OUT $KERNEL > $R/gpurun_out/pmc_summary_$KERNEL.json; cat $R/gpurun_out/pmc_summary_$KERNEL.json
+python3 $R/scripts/summarize_pmc.py $OUT $KERNEL > $R/gpurun_out/pmc_summary_$KERNEL.json
+python3 $R/scripts/collect_traffic.py $R/gpurun_out/pmc_summary_$KERNEL.json $KERNEL $R/gpurun_out/traffic_$KERNEL.json

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box session: build, GPU tests, smoke, bench, rocprofv3 kernel trace.  Run via gpurun.
+# One full GPU-box session: build, GPU tests, smoke, PMC passes (-> traffic json), bench, rocprofv3 kernel trace.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
@@ -7,10 +7,14 @@ mkdir -p $OUT
 cd $R
 python -c "import __graft_entry__ as g; g.build()" || exit 1
 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
-tail -5 $OUT/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
+tail -4 $OUT/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
+bash scripts/collect_pmc.sh persistent > $OUT/pmc.log 2>&1; echo "pmc rc=$?"; tail -2 $OUT/pmc.log
+cp $OUT/traffic_persistent.json $R/profiles/traffic_latest.json
+cd $R
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
-python bench.py --steps 10 --warmup 2 --kernel brute --no-cpu-baseline > $OUT/bench_brute.json 2>> $OUT/bench.err; cat $OUT/bench_brute.json
+PTAMD_BENCH_FORCE_GATHER=1 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_gather.json 2>> $OUT/bench.err; echo "bench+gather rc=$?"; cut -c1-300 $OUT/bench_gather.json
+for k in bvh blockwise brute; do python bench.py --steps 10 --warmup 2 --kernel $k --no-cpu-baseline > $OUT/bench_$k.json 2>> $OUT/bench.err; cut -c1-260 $OUT/bench_$k.json; echo; done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kernel -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_kernel.log 2>&1; echo "rocprof rc=$?"
-find $OUT/prof_kernel -name "*stats*" | head
+find $OUT/prof_kernel -name "*kernel_stats*" | head -2

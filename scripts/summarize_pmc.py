@@ -11,8 +11,14 @@ for f in glob.glob(os.path.join(out_dir, "pass*", "**", "*counter_collection.csv
             if "pt_megakernel" not in name:
                 continue
             nm = name.replace(" ", "")
-            if "true>(ptamd::KParams)" in nm or ",true," in nm.split("pt_megakernel")[1][:40].replace("<2,true,", "<2,X,").replace("<1,true,", "<1,X,"):
-                continue   # STATS=true variant
+            targs = nm.split("<", 1)[1].split(">", 1)[0].split(",") if "<" in nm else []
+            bools = [t for t in targs if t in ("true", "false")]
+            if len(bools) >= 2 and bools[1] == "true":      # <.., LDS_RESIDENT, STATS, ..>: skip instrumented launches
+                continue
+            want = {"bvh": "pt_megakernel<", "brute": "pt_megakernel<", "persistent": "pt_megakernel_persistent<",
+                    "blockwise": "pt_megakernel_blockwise<"}.get(kernel)
+            if want and want not in nm:
+                continue
             c = row["Counter_Name"]; v = float(row["Counter_Value"])
             s = acc.setdefault(c, [0.0, 0])
             s[0] += v; s[1] += 1
