@@ -13,5 +13,6 @@ from .scene import (HostScene, cubemap_for_scene, cubemap_from_color, cubemap_fr
 from .render import (Context, FrameRenderer, host_bvh_trace, wang_hash, REFERENCE_BOUNCES,
                      POST_NONE, POST_GRAYSCALE, POST_SEPIA, POST_INVERT)
 from .tiles import row_bands, band_of_rank, BandGather
+from .synthetic import tessellate
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -147,6 +147,17 @@ PT_DEV uint32_t pt_f2u(float v)
 
 struct Xorwow { uint32_t v0, v1, v2, v3, v4, d; };
 
+// raytrace.cu:275-285 (host function in the reference; batched launches evaluate it per sample)
+PT_DEV uint32_t wang_hash(uint32_t a)
+{
+  a = (a ^ 61u) ^ (a >> 16);
+  a = a + (a << 3);
+  a = a ^ (a >> 4);
+  a = a * 0x27d4eb2du;
+  a = a ^ (a >> 15);
+  return a;
+}
+
 PT_DEV void xorwow_init(Xorwow& st, uint32_t seed)
 {
   uint32_t s0 = seed ^ 0xaad26b49u;
@@ -208,6 +219,11 @@ struct KParams {
   uint32_t* tile_counter;
   uint32_t tiles_x, n_tiles, tiles_per_ticket;
   uint32_t refill_min; // idle lanes that trigger a refill (1..64)
+  // batched frames (persistent variant): `sample_count` consecutive static frames in one launch.
+  // Sample k of a pixel uses hash_seed = WangHash(frame_nb0 + k); its clamped radiance goes to
+  // samples_out[k][band row][x] and pt_resolve_kernel applies them to the accumulator in frame order.
+  uint32_t sample_count, frame_nb0;
+  float* samples_out;
 };
 
 // one intersect() result carried through radiance()

@@ -358,15 +358,18 @@ struct Path {
   float specular_col; // carried over between iterations
   int b;
   uint32_t x, y;
+  uint32_t k; // sample index inside a batched launch (0 otherwise)
 };
 
 // kernel() prologue: seed, generateRay, camera_dof (raytrace.cu:227-240)
-PT_DEV void path_begin(const KParams& p, uint32_t x, uint32_t y, Path& st)
+PT_DEV void path_begin(const KParams& p, uint32_t x, uint32_t y, Path& st, uint32_t k = 0)
 {
   // raytrace.cu:227-229 with the reference's launch geometry (16x16 blocks, padded grid)
   const uint32_t grid_x = p.width / 16u + 1u;
   const uint32_t tid = ((x >> 4) + (y >> 4) * grid_x) * 256u + (y & 15u) * 16u + (x & 15u);
-  xorwow_init(st.rng, p.hash_seed + tid);
+  // k > 0 only in batched launches: frame frame_nb0 + k has hash_seed WangHash(frame_nb0 + k) (raytrace.cu:321)
+  const uint32_t hash_seed = k == 0 ? p.hash_seed : wang_hash(p.frame_nb0 + k);
+  xorwow_init(st.rng, hash_seed + tid);
 
   // generateRay (intersection.cuh:75-97), pixel-invariant terms precomputed on the host
   const int half_w = (int)(p.width / 2u), half_h = (int)(p.height / 2u);
@@ -390,6 +393,7 @@ PT_DEV void path_begin(const KParams& p, uint32_t x, uint32_t y, Path& st)
   st.b = 0;
   st.x = x;
   st.y = y;
+  st.k = k;
 }
 
 // One iteration of radiance()'s loop (raytrace.cu:67-207) is split around the nearest-hit search
@@ -565,6 +569,15 @@ PT_DEV void path_finish(const KParams& p, const Path& st)
   p.surface[(size_t)(y - p.surf_row0) * p.width + x] = px;
 }
 
+// Batched launches: the clamped sample (raytrace.cu:248) is parked; pt_resolve_kernel applies the
+// samples of a pixel to the accumulator in frame order, which is what consecutive launches do.
+PT_DEV void path_finish_sample(const KParams& p, const Path& st)
+{
+  const uint32_t rows = p.row_end - p.row_begin;
+  float* sp = p.samples_out + (((size_t)st.k * rows + (st.y - p.row_begin)) * p.width + st.x) * 3;
+  sp[0] = clamp01(st.acc.x); sp[1] = clamp01(st.acc.y); sp[2] = clamp01(st.acc.z);
+}
+
 template <bool STATS>
 PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t samples)
 {
@@ -659,7 +672,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
   // first ticket is its own global wave index (no atomic), later ones come from the shared
   // counter, which starts at the number of waves.  One returning atomic per ~256+ pixels keeps
   // the single counter far below its ~88 dequeues/us saturation point (MI355X_MICROARCH.md).
-  uint32_t tile_x0 = 0, tile_y0 = 0, qpos = 64;
+  uint32_t tile_x0 = 0, tile_y0 = 0, tile_k = 0, qpos = 64;
   uint32_t tile = 0, tile_end = 0; // tiles [tile, tile_end) of the current ticket remain
   uint32_t ticket = blockIdx.x * (PT_PERSISTENT_THREADS / 64u) + (threadIdx.x >> 6);
   bool have_ticket = true;         // `ticket` not yet expanded into tiles
@@ -669,7 +682,8 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
     const unsigned long long idle_mask = __ballot(idle);
     if ((uint32_t)__popcll(idle_mask) >= p.refill_min || idle_mask == ~0ull) {
       if (idle && has_output) {
-        path_finish(p, st);
+        if (p.sample_count > 1u) path_finish_sample(p, st);
+        else path_finish(p, st);
         has_output = false;
         if (STATS) samples++;
       }
@@ -685,12 +699,15 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
             }
             have_ticket = false;
             tile = ticket * p.tiles_per_ticket;
-            if (tile >= p.n_tiles) { exhausted = true; break; }
+            const uint32_t total = p.n_tiles * p.sample_count; // tiles of sample 0, then sample 1, ...
+            if (tile >= total) { exhausted = true; break; }
             tile_end = tile + p.tiles_per_ticket;
-            if (tile_end > p.n_tiles) tile_end = p.n_tiles;
+            if (tile_end > total) tile_end = total;
           }
-          tile_x0 = (tile % p.tiles_x) * 8u;
-          tile_y0 = p.row_begin + (tile / p.tiles_x) * 8u;
+          tile_k = tile / p.n_tiles;
+          const uint32_t tl = tile - tile_k * p.n_tiles;
+          tile_x0 = (tl % p.tiles_x) * 8u;
+          tile_y0 = p.row_begin + (tl / p.tiles_x) * 8u;
           ++tile;
           qpos = 0;
         }
@@ -700,7 +717,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
           const uint32_t k = qpos + rank;
           const uint32_t x = tile_x0 + (k & 7u), y = tile_y0 + (k >> 3);
           if (x < p.width && y < p.row_end) {
-            path_begin(p, x, y, st);
+            path_begin(p, x, y, st, tile_k);
             idle = false;
             has_output = true;
           }
@@ -876,6 +893,35 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
   flush_counters<STATS>(p, cnt, samples);
 }
 
+// Second kernel of a batched launch: per pixel, apply the parked samples to the temporal
+// framebuffer in frame order — t = t * is_static + s_k for k = 0..count-1, exactly what `count`
+// consecutive launches do (raytrace.cu:255-256, is_static == 1) — then tonemap once with the last
+// frame number (the intermediate surfaces of frames 0..count-2 would be overwritten anyway).
+__global__ void __launch_bounds__(256) pt_resolve_kernel(const KParams p)
+{
+  const uint32_t rows = p.row_end - p.row_begin;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= rows * p.width) return;
+  const uint32_t x = i % p.width, y = p.row_begin + i / p.width;
+  const size_t ti = (size_t)(p.height - y - 1u - p.tfb_row0) * p.width + x;
+  float* tp = p.tfb + ti * 3;
+  f3 t = mk3(tp[0], tp[1], tp[2]);
+  for (uint32_t k = 0; k < p.sample_count; ++k) {
+    const float* sp = p.samples_out + (((size_t)k * rows + (y - p.row_begin)) * p.width + x) * 3;
+    t = t * (float)p.is_static;
+    t = t + mk3(sp[0], sp[1], sp[2]);
+  }
+  tp[0] = t.x; tp[1] = t.y; tp[2] = t.z;
+  f3 rad = t / p.frame_nb_f; // (float)(frame_nb0 + count - 1)
+  rad = exposure(rad);
+  const float g = 1.0f / 2.2f;
+  rad = mk3(pt_powf(rad.x, g), pt_powf(rad.y, g), pt_powf(rad.z, g));
+  rad = post_process(p.post_id, rad);
+  const uint32_t px = (pt_f2u(rad.x * 255.0f) & 0xffu) | ((pt_f2u(rad.y * 255.0f) & 0xffu) << 8) |
+                      ((pt_f2u(rad.z * 255.0f) & 0xffu) << 16);
+  p.surface[(size_t)(y - p.surf_row0) * p.width + x] = px;
+}
+
 // Nearest-hit query on explicit rays (tests: BVH vs brute force on the device).
 template <int KIND>
 __global__ void __launch_bounds__(256) pt_trace_rays_kernel(const KParams p, const float* rays, uint32_t n, int4* out)
@@ -1004,6 +1050,14 @@ hipError_t launch_megakernel_blockwise(const KParams& p, bool lds_resident, size
   KParams pc = p;
   void* args[] = { &pc };
   return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_BW_THREADS), args, lds, stream);
+}
+
+hipError_t launch_resolve(const KParams& p, hipStream_t stream)
+{
+  const uint32_t n = (p.row_end - p.row_begin) * p.width;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(pt_resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, p);
+  return hipGetLastError();
 }
 
 hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,

@@ -59,6 +59,8 @@ struct ptamd_context {
   int n_cus = 0;
   int blocks_per_cu[2] = { -1, -1 }; // [lds_resident]
   int bw_blocks_per_cu[2] = { -1, -1 };
+  float* d_samples = nullptr; // parked samples of batched launches (grown on demand)
+  size_t samples_bytes = 0;
   uint32_t default_kernel = PTAMD_KERNEL_BVH_PERSISTENT; // what PTAMD_KERNEL_AUTO means
   uint32_t refill_min = 64;
   uint32_t tiles_per_ticket = 1;
@@ -135,6 +137,8 @@ int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
   if (l->row_begin > l->row_end || l->row_end > l->height) { set_error("ptamd_raytrace: bad row band"); return PTAMD_ERR_ARG; }
   if (l->frame_nb == 0) { set_error("ptamd_raytrace: frame_nb must be >= 1"); return PTAMD_ERR_ARG; }
   if (l->bounces == 0 || l->bounces > 1024) { set_error("ptamd_raytrace: bounces out of range (1..1024)"); return PTAMD_ERR_ARG; }
+  if (l->frame_count > 4096) { set_error("ptamd_raytrace: frame_count out of range (<= 4096)"); return PTAMD_ERR_ARG; }
+  if (l->frame_count > 1 && l->moved) { set_error("ptamd_raytrace: batched frames must be static (moved = 0)"); return PTAMD_ERR_ARG; }
   if (l->kernel > PTAMD_KERNEL_BVH_BLOCKWISE) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
   return PTAMD_OK;
 }
@@ -187,6 +191,10 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   hipStream_t stream = static_cast<hipStream_t>(l->stream);
   hipError_t e;
   const uint32_t which = l->kernel == PTAMD_KERNEL_AUTO ? ctx->default_kernel : l->kernel;
+  if (l->frame_count > 1 && which != PTAMD_KERNEL_BVH_PERSISTENT) {
+    set_error("ptamd_raytrace: frame_count > 1 needs the persistent kernel (PTAMD_KERNEL_AUTO or _BVH_PERSISTENT)");
+    return PTAMD_ERR_ARG;
+  }
   if (which == PTAMD_KERNEL_BVH_BLOCKWISE) {
     // persistent workgroups over 32x16 super-tiles; tickets 0..n_blocks-1 are static
     const uint32_t rows = l->row_end - l->row_begin;
@@ -205,6 +213,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)n_blocks, 1, stream));
     e = launch_megakernel_blockwise(p, resident, lds, stats, n_blocks, stream);
   } else if (which == PTAMD_KERNEL_BVH_PERSISTENT) {
+    const uint32_t count = l->frame_count > 1 ? l->frame_count : 1u;
 
     const uint32_t rows = l->row_end - l->row_begin;
     p.tiles_x = (l->width + 7u) / 8u;
@@ -217,7 +226,22 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     }
     const uint32_t waves_per_block = kPersistentThreads / 64u;
     uint32_t n_blocks = (uint32_t)ctx->n_cus * (uint32_t)bpc;
-    const uint32_t n_tickets = (p.n_tiles + ctx->tiles_per_ticket - 1u) / ctx->tiles_per_ticket;
+    p.sample_count = count;
+    p.frame_nb0 = l->frame_nb;
+    if (count > 1) {
+      // seeds of frames frame_nb+1.. are hashed on the device; the tonemap uses the last frame number
+      p.frame_nb_f = (float)(int)(l->frame_nb + count - 1u);
+      const size_t need = (size_t)count * rows * l->width * 3u * sizeof(float);
+      if (need > ctx->samples_bytes) {
+        PT_HIP(hipStreamSynchronize(stream)); // earlier launches may still use the old buffer
+        (void)hipFree(ctx->d_samples);
+        ctx->d_samples = nullptr; ctx->samples_bytes = 0;
+        PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_samples), need));
+        ctx->samples_bytes = need;
+      }
+      p.samples_out = ctx->d_samples;
+    }
+    const uint32_t n_tickets = (p.n_tiles * count + ctx->tiles_per_ticket - 1u) / ctx->tiles_per_ticket;
     const uint32_t useful = (n_tickets + waves_per_block - 1u) / waves_per_block;
     if (n_blocks > useful) n_blocks = useful;
     p.refill_min = ctx->refill_min;
@@ -226,6 +250,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     p.tile_counter = ctx->d_tickets + (ctx->ticket_next++ % kTicketRing);
     PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)(n_blocks * waves_per_block), 1, stream));
     e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
+    if (e == hipSuccess && count > 1) e = launch_resolve(p, stream);
   } else {
     e = launch_megakernel(p, kind, resident, lds, stats, stream);
   }
@@ -298,6 +323,7 @@ void ptamd_destroy(ptamd_context* ctx)
   for (auto& c : ctx->cubemaps) (void)hipFree(c.faces);
   (void)hipFree(ctx->d_stats);
   (void)hipFree(ctx->d_tickets);
+  (void)hipFree(ctx->d_samples);
   delete ctx;
 }
 

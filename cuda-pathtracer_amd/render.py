@@ -116,7 +116,7 @@ class Context:
                     width: int, height: int, frame_nb: int, bounces: int = REFERENCE_BOUNCES,
                     moved: bool = False, post_id: int = POST_NONE, stream=None,
                     rows: Optional[tuple] = None, kernel: int = N.KERNEL_AUTO,
-                    band_local_buffers: bool = False) -> N.Launch:
+                    band_local_buffers: bool = False, frame_count: int = 1) -> N.Launch:
         l = N.Launch()
         l.surface_rgba8 = _ptr(array)
         l.temporal_framebuffer = _ptr(temporal_framebuffer)
@@ -128,6 +128,7 @@ class Context:
         l.frame_nb, l.bounces = frame_nb, bounces
         l.moved, l.post_id, l.kernel = (1 if moved else 0), post_id, kernel
         l.band_local_buffers = 1 if band_local_buffers else 0
+        l.frame_count = frame_count
         return l
 
     def raytrace_ex(self, launch: N.Launch) -> None:
@@ -187,7 +188,16 @@ class FrameRenderer:
         self.surface.zero_()
 
     def render(self, spp: int, bounces: int = REFERENCE_BOUNCES, post_id: int = POST_NONE,
-               kernel: int = N.KERNEL_AUTO, stream=None, first_frame: int = 1) -> None:
+               kernel: int = N.KERNEL_AUTO, stream=None, first_frame: int = 1, batched: bool = False) -> None:
+        """`batched=True` issues the spp frames as ONE launch (ptamd_launch.frame_count): same
+        accumulator and final surface bit for bit, no kernel tails between frames."""
+        if batched and spp > 1:
+            l = self.ctx.make_launch(self.surface, self.accum, self.scene_id, self.cubemap_id, self.cam,
+                                     self.width, self.height, frame_nb=first_frame, bounces=bounces, post_id=post_id,
+                                     stream=stream, rows=self.rows, kernel=kernel,
+                                     band_local_buffers=self.band_local, frame_count=spp)
+            self.ctx.raytrace_ex(l)
+            return
         for k in range(first_frame, first_frame + spp):
             l = self.ctx.make_launch(self.surface, self.accum, self.scene_id, self.cubemap_id, self.cam,
                                      self.width, self.height, frame_nb=k, bounces=bounces, post_id=post_id,

@@ -186,6 +186,10 @@ typedef struct {
   uint32_t post_id;            /* 0 none, 1 grayscale, 2 sepia, 3 invert (raytrace.cu:327-357) */
   uint32_t kernel;             /* ptamd_kernel_kind */
   uint32_t band_local_buffers; /* 0: buffers are full-frame; 1: they hold only the row band */
+  uint32_t frame_count;        /* 0 or 1: one frame.  N > 1 (static frames, persistent kernel only): frames
+                                  frame_nb .. frame_nb+N-1 in ONE launch — same accumulator and final surface
+                                  as N consecutive calls, bit for bit; intermediate surfaces are not produced */
+  uint32_t _reserved;
 } ptamd_launch;
 
 int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch);

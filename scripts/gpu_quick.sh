@@ -3,7 +3,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 run() { python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>>$OUT/bench.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('$LABEL', d['config']['kernel'], d['value'], 'Msamples/s', 'kernel', r['kernel_ms_per_launch'], 'ms', d['rgba_checksum_rank0_band'])"; }
+print('$LABEL', d['config']['kernel'], d['value'], 'Msamples/s', d['ms_per_frame'], 'ms/frame kernel', r['kernel_ms_per_launch'], 'ms', d['rgba_checksum_rank0_band'])"; }
 python -c "import __graft_entry__ as g; g.build()" || exit 1
 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
-for k in persistent bvh blockwise; do LABEL=default run --kernel $k; done
+LABEL=batched run --kernel persistent
+LABEL=sequential run --kernel persistent --sequential
+LABEL=band135-batched run --kernel persistent --height 135
+LABEL=band135-seq run --kernel persistent --height 135 --sequential

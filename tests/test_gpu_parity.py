@@ -179,6 +179,37 @@ def test_row_band_split_is_bit_identical(P, gpu_ctx, indoor):
     assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), full_acc, full_rgba, "band launches into full buffers")
 
 
+def test_batched_frames_equal_consecutive_launches(P, O, gpu_ctx, indoor):
+    """ptamd_launch.frame_count = N: one launch + resolve == N consecutive raytrace() calls, bit for bit
+    (accumulator and final surface), also on top of a non-zero accumulator and for row bands."""
+    import torch
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    for (W, H, spp, B, post, rows, band_local) in ((200, 121, 4, 4, 0, None, False), (97, 50, 7, 3, 2, (13, 41), True),
+                                                  (1920, 1080, 4, 4, 0, None, False)):
+        seq = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H, rows=rows, band_local=band_local)
+        bat = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H, rows=rows, band_local=band_local)
+        seq.render(spp=2, bounces=B, post_id=post)                       # pre-existing accumulation
+        bat.render(spp=2, bounces=B, post_id=post)
+        seq.render(spp=spp, bounces=B, post_id=post, first_frame=3)
+        bat.render(spp=spp, bounces=B, post_id=post, first_frame=3, batched=True)
+        torch.cuda.synchronize()
+        assert_same(bat.accum.cpu().numpy(), bat.surface.cpu().numpy(), seq.accum.cpu().numpy(), seq.surface.cpu().numpy(),
+                    f"batched {W}x{H} spp{spp}")
+    # oracle check of the batched path itself
+    ref = O.render(O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera), 80, 48, spp=5, bounces=3)
+    fr = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), 80, 48)
+    fr.render(spp=5, bounces=3, batched=True)
+    torch.cuda.synchronize()
+    assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref, "batched vs oracle")
+    l = gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), 80, 48, frame_nb=1, frame_count=3, moved=True)
+    with pytest.raises(P.PtamdError):
+        gpu_ctx.raytrace_ex(l)
+    l = gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), 80, 48, frame_nb=1, frame_count=3, kernel=P.KERNEL_BVH)
+    with pytest.raises(P.PtamdError):
+        gpu_ctx.raytrace_ex(l)
+
+
 def test_trace_rays_device_equals_oracle(P, O, gpu_ctx):
     """Nearest-hit records (kind, index, t bits) of both device traversals == brute-force oracle,
     including light spheres."""
@@ -246,6 +277,28 @@ def test_full_size_properties_1080p_4spp_4bounces(P, O, gpu_ctx, indoor):
     np.testing.assert_array_equal(bvh_acc[H - rows[1]:H - rows[0]].view(np.uint32), ref_acc[H - rows[1]:H - rows[0]].view(np.uint32))
     assert (bvh_rgba[..., 3] == 0).all() and bvh_acc.max() <= 4.0 and bvh_acc.min() >= 0.0
     torch.cuda.synchronize()
+
+
+def test_config4_sponza_class_deep_bvh(P, O, gpu_ctx, indoor):
+    """BASELINE.json configs[3] geometry: indoor.obj tessellated 24x24 per face = 256 896 triangles
+    (nodes + triangles = 28 MB: the L2-resident variant).  Oracle = brute force over every face,
+    feasible only on a small frame; the full-size frame is checked BVH kernel vs BVH kernel variants."""
+    big = P.tessellate(indoor, 24)
+    assert len(big.faces) == 256896
+    cube = P.cubemap_for_scene(big)
+    ids = (gpu_ctx.upload_scene(big), gpu_ctx.upload_cubemap(cube))
+    info = gpu_ctx.scene_info(ids[0])
+    assert info["lds_bytes_bvh"] > 20 * 1024 * 1024 and info["depth"] >= 18
+    ref = O.render(O.OracleScene.from_host_scene(big, cube), O.camera_from_record(big.camera), 64, 36, spp=1, bounces=3)
+    for k in (P.KERNEL_AUTO, P.KERNEL_BVH, P.KERNEL_BVH_BLOCKWISE):
+        acc, rgba = gpu_render(P, gpu_ctx, big, cube, 64, 36, 1, 3, k, ids=ids)
+        assert_same(acc, rgba, *ref, f"sponza-class kernel {k}")
+    a0, r0 = gpu_render(P, gpu_ctx, big, cube, 1920, 1080, 1, 4, P.KERNEL_AUTO, ids=ids)
+    a1, r1 = gpu_render(P, gpu_ctx, big, cube, 1920, 1080, 1, 4, P.KERNEL_BVH, ids=ids)
+    assert_same(a0, r0, a1, r1, "sponza-class 1080p persistent vs tile")
+    # tessellation keeps every surface where it was: the image is close to (not equal to) the 446-face one
+    b0, q0 = gpu_render(P, gpu_ctx, indoor, cube, 1920, 1080, 1, 4, P.KERNEL_AUTO)
+    assert np.abs(a0.mean() - b0.mean()) < 0.01
 
 
 def test_stats_are_consistent(P, O, gpu_ctx, indoor):
