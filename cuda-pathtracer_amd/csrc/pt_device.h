@@ -198,7 +198,7 @@ struct KParams {
   const float* texels;
   const float4* cubemap;    // 6 * size * size
   uint32_t cubemap_size;
-  uint32_t n_faces, n_lights, n_nodes;
+  uint32_t n_faces, n_lights, n_nodes, n_bvh_tris;
   // camera, pixel-invariant part of generateRay hoisted to the host (same float ops)
   f3 cam_pos, cam_p0, cam_u, cam_v; // p0 = position + dir * screen_dist
   float focus_dist, aperture;

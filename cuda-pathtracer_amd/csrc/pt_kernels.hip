@@ -602,7 +602,7 @@ PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes,
       s_tris = s_mem;
     } else {
       stage_to_lds(s_mem, p.nodes, p.n_nodes * 4);
-      stage_to_lds(s_mem + p.n_nodes * 4, p.tris_bvh, p.n_faces * 3);
+      stage_to_lds(s_mem + p.n_nodes * 4, p.tris_bvh, p.n_bvh_tris * 3);
       s_nodes = s_mem;
       s_tris = s_mem + p.n_nodes * 4;
     }
@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
   const float4* s_tris;
   stage_scene<2, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris);
   // behind the staged scene: ray pool (2 float4 per slot), count table, pool head, ticket
-  float4* pool = s_mem + (LDS_RESIDENT ? (p.n_nodes * 4u + p.n_faces * 3u) : 0u);
+  float4* pool = s_mem + (LDS_RESIDENT ? (p.n_nodes * 4u + p.n_bvh_tris * 3u) : 0u);
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(pool + PT_BW_THREADS * 2u);
   uint32_t* s_head = s_cnt + 128;
   uint32_t* s_ticket = s_cnt + 129;

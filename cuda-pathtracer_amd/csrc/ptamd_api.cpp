@@ -35,6 +35,7 @@ struct DeviceScene {
   TexDesc* textures = nullptr;
   float* texels = nullptr;
   uint32_t n_faces = 0, n_lights = 0, n_nodes = 0, n_materials = 0, n_textures = 0;
+  uint32_t n_bvh_tris = 0; // triangle records behind the BVH leaves (>= n_faces with split references)
   ptamd_scene_info info{};
 };
 
@@ -156,7 +157,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   p.nodes = s.nodes; p.tris_bvh = s.tris_bvh; p.tris_brute = s.tris_brute; p.shade = s.shade;
   p.materials = s.materials; p.lights = s.lights; p.textures = s.textures; p.texels = s.texels;
   p.cubemap = cm.faces; p.cubemap_size = cm.size;
-  p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes;
+  p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
 
   // generateRay's pixel-invariant part (intersection.cuh:79-89)
   const ptamd_camera& cam = l->camera;
@@ -389,7 +390,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
 
   PT_HIP(hipSetDevice(ctx->device));
   DeviceScene d;
-  d.n_faces = sc->n_faces; d.n_lights = sc->n_lights; d.n_nodes = bvh.n_nodes;
+  d.n_faces = sc->n_faces; d.n_lights = sc->n_lights; d.n_nodes = bvh.n_nodes; d.n_bvh_tris = bvh.n_tris;
   d.n_materials = sc->n_materials; d.n_textures = sc->n_textures;
   if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
       (rc = upload(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4)) ||
@@ -405,7 +406,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   d.info.n_faces = sc->n_faces; d.info.n_lights = sc->n_lights; d.info.n_nodes = bvh.n_nodes;
   d.info.n_leaves = bvh.n_leaves; d.info.max_leaf_size = bvh.max_leaf; d.info.depth = bvh.depth;
   d.info.node_bytes = 64; d.info.tri_bytes = 48;
-  d.info.lds_bytes_bvh = bvh.n_nodes * 64u + sc->n_faces * 48u;
+  d.info.lds_bytes_bvh = bvh.n_nodes * 64u + bvh.n_tris * 48u;
   d.info.lds_bytes_brute = sc->n_faces * 48u;
   ctx->scenes.push_back(d);
   *out_scene_id = (uint32_t)ctx->scenes.size() - 1;
@@ -499,7 +500,7 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   KParams p;
   std::memset(&p, 0, sizeof p);
   p.nodes = s.nodes; p.tris_bvh = s.tris_bvh; p.tris_brute = s.tris_brute; p.lights = s.lights;
-  p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes;
+  p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
   float* d_rays = nullptr;
   int4* d_out = nullptr;
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));

@@ -178,6 +178,90 @@ struct Builder {
   }
 };
 
+// Clips a convex polygon (double coordinates) against the half-space  x[axis] <= pos  (keep_low)
+// or  x[axis] >= pos.
+void clip_polygon(const std::vector<double>& in, int axis, double pos, bool keep_low, std::vector<double>& out)
+{
+  out.clear();
+  const size_t n = in.size() / 3;
+  for (size_t i = 0; i < n; ++i) {
+    const double* a = &in[i * 3];
+    const double* b = &in[((i + 1) % n) * 3];
+    const bool ia = keep_low ? a[axis] <= pos : a[axis] >= pos;
+    const bool ib = keep_low ? b[axis] <= pos : b[axis] >= pos;
+    if (ia) out.insert(out.end(), a, a + 3);
+    if (ia != ib) {
+      const double t = (pos - a[axis]) / (b[axis] - a[axis]);
+      double c[3] = { a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), a[2] + t * (b[2] - a[2]) };
+      c[axis] = pos;
+      out.insert(out.end(), c, c + 3);
+    }
+  }
+}
+
+// alpha: a reference is split while the half-area of its box exceeds alpha * (half-area of the
+// scene box); budget: at most this many extra references.
+void split_references(std::vector<Prim>& prims, const ptamd_face* faces, float alpha, uint32_t budget)
+{
+  if (!(alpha > 0.f) || budget == 0 || prims.empty()) return;
+  Box scene;
+  scene.reset();
+  for (const Prim& p : prims) scene.grow(p.box);
+  const float threshold = alpha * scene.half_area();
+  struct Item { Prim prim; std::vector<double> poly; };
+  std::vector<Item> work;
+  std::vector<Prim> done;
+  for (const Prim& p : prims) {
+    if (p.box.half_area() > threshold) {
+      Item it;
+      it.prim = p;
+      for (int k = 0; k < 3; ++k)
+        for (int a = 0; a < 3; ++a) it.poly.push_back((double)(&faces[p.face].vertices[k].x)[a]);
+      work.push_back(std::move(it));
+    } else {
+      done.push_back(p);
+    }
+  }
+  uint32_t extra = 0;
+  std::vector<double> lo_poly, hi_poly;
+  while (!work.empty()) {
+    // largest first
+    size_t big = 0;
+    for (size_t i = 1; i < work.size(); ++i)
+      if (work[i].prim.box.half_area() > work[big].prim.box.half_area()) big = i;
+    Item it = std::move(work[big]);
+    work.erase(work.begin() + (long)big);
+    if (extra >= budget || !(it.prim.box.half_area() > threshold)) { done.push_back(it.prim); continue; }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+      if (it.prim.box.hi[a] - it.prim.box.lo[a] > it.prim.box.hi[axis] - it.prim.box.lo[axis]) axis = a;
+    const double pos = 0.5 * ((double)it.prim.box.lo[axis] + (double)it.prim.box.hi[axis]);
+    clip_polygon(it.poly, axis, pos, true, lo_poly);
+    clip_polygon(it.poly, axis, pos, false, hi_poly);
+    if (lo_poly.size() < 9 || hi_poly.size() < 9) { done.push_back(it.prim); continue; } // degenerate: keep whole
+    const std::vector<double>* halves[2] = { &lo_poly, &hi_poly };
+    for (int h = 0; h < 2; ++h) {
+      Item c;
+      c.prim.face = it.prim.face;
+      c.prim.box.reset();
+      c.poly = *halves[h];
+      for (size_t i = 0; i < c.poly.size(); i += 3)
+        for (int a = 0; a < 3; ++a) {
+          // round outwards when narrowing to float; the clipped box never exceeds the parent's
+          const float f = (float)c.poly[i + a];
+          const float flo = (double)f > c.poly[i + a] ? std::nextafter(f, -std::numeric_limits<float>::infinity()) : f;
+          const float fhi = (double)f < c.poly[i + a] ? std::nextafter(f, std::numeric_limits<float>::infinity()) : f;
+          c.prim.box.lo[a] = std::max(std::min(c.prim.box.lo[a], flo), it.prim.box.lo[a]);
+          c.prim.box.hi[a] = std::min(std::max(c.prim.box.hi[a], fhi), it.prim.box.hi[a]);
+        }
+      for (int a = 0; a < 3; ++a) c.prim.c[a] = 0.5f * c.prim.box.lo[a] + 0.5f * c.prim.box.hi[a];
+      work.push_back(std::move(c));
+    }
+    ++extra;
+  }
+  prims.swap(done);
+}
+
 inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
@@ -186,6 +270,10 @@ inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t max_leaf, Bvh& out)
 {
   out = Bvh();
+  float split_alpha = 0.0f;   // pre-splitting off unless asked for (tuning knobs)
+  uint32_t split_budget = n_faces / 2u + 16u;
+  if (const char* e = std::getenv("PTAMD_BVH_SPLIT_ALPHA")) split_alpha = (float)std::atof(e);
+  if (const char* e = std::getenv("PTAMD_BVH_SPLIT_BUDGET")) split_budget = (uint32_t)std::atoi(e);
   if (n_faces == 0) return PTAMD_OK;
   if (n_faces >= (1u << 24)) { set_error("build_bvh: more than 2^24 faces"); return PTAMD_ERR_LIMIT; }
   if (const char* e = std::getenv("PTAMD_BVH_MAX_LEAF")) max_leaf = (uint32_t)std::atoi(e);   // tuning knobs
@@ -212,8 +300,15 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
       p.c[a] = 0.5f * p.box.lo[a] + 0.5f * p.box.hi[a];
     }
   }
-  b.nodes.reserve(2 * n_faces);
-  b.build(0, n_faces, 0);
+  // ---- reference pre-splitting ("early split clipping"): a few huge faces (walls, floor) would
+  // otherwise bloat every ancestor box.  Such a face is represented by several REFERENCES, each
+  // with the tight box of (face clipped to a sub-box); all of them point at the same triangle
+  // record, so Moller-Trumbore and the (t, index) minimum are untouched — a face tested twice
+  // yields the same candidate twice.
+  split_references(b.prims, faces, split_alpha, split_budget);
+  const uint32_t n_refs = (uint32_t)b.prims.size();
+  b.nodes.reserve(2 * n_refs);
+  b.build(0, n_refs, 0);
 
   // ---- flatten: DFS pre-order, left child first
   const uint32_t n_nodes = (uint32_t)b.nodes.size();
@@ -236,7 +331,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   out.n_nodes = n_nodes;
   out.depth = b.depth;
   out.nodes.assign((size_t)n_nodes * 16, 0.0f);
-  out.tris.assign((size_t)n_faces * 12, 0.0f);
+  out.tris.assign((size_t)n_refs * 12, 0.0f); // upper bound; trimmed after the leaves are written
 
   // per-octant miss links: top-down.  miss[o] of the root is END.
   std::vector<uint32_t> miss((size_t)n_nodes * 8, 0xFFFFFFFFu);
@@ -263,13 +358,14 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
     }
     uint32_t info = 0, child = 0;
     if (bn.left < 0) {
-      info = tri_cursor | (bn.count << 24);
       out.n_leaves++;
-      out.max_leaf = std::max(out.max_leaf, bn.count);
       // triangles of a leaf in ascending global face index
       std::vector<uint32_t> ids;
       for (uint32_t i = 0; i < bn.count; ++i) ids.push_back(b.prims[bn.first + i].face);
       std::sort(ids.begin(), ids.end());
+      ids.erase(std::unique(ids.begin(), ids.end()), ids.end()); // two references of one face in one leaf
+      info = tri_cursor | ((uint32_t)ids.size() << 24);
+      out.max_leaf = std::max(out.max_leaf, (uint32_t)ids.size());
       for (uint32_t fi : ids) {
         const ptamd_face& f = faces[fi];
         float* t = &out.tris[(size_t)tri_cursor * 12];
@@ -291,6 +387,8 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
     q[7] = u2f(child);
     for (int o = 0; o < 8; ++o) q[8 + o] = u2f(miss[(size_t)k * 8 + o]);
   }
+  out.tris.resize((size_t)tri_cursor * 12);
+  out.n_tris = tri_cursor;
   return PTAMD_OK;
 }
 

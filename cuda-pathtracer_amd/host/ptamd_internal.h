@@ -43,6 +43,7 @@ struct Bvh {
   std::vector<float> nodes;      // 16 floats per node
   std::vector<float> tris;       // 12 floats per triangle, leaf-major
   uint32_t n_nodes = 0, n_leaves = 0, max_leaf = 0, depth = 0;
+  uint32_t n_tris = 0;           // triangle records (>= faces when references were split)
 };
 
 constexpr uint32_t kBvhEnd = 0xFFFFu;

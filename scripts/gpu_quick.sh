@@ -7,6 +7,4 @@ print('$LABEL', d['config']['kernel'], d['value'], 'Msamples/s', d['ms_per_frame
 python -c "import __graft_entry__ as g; g.build()" || exit 1
 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
 LABEL=batched run --kernel persistent
-LABEL=sequential run --kernel persistent --sequential
-LABEL=band135-batched run --kernel persistent --height 135
-LABEL=band135-seq run --kernel persistent --height 135 --sequential
+LABEL=tile run --kernel bvh

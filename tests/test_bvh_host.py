@@ -76,3 +76,26 @@ def test_degenerate_inputs(P, O):
     flat = make_scene(P, quad)
     rays[:, 3:] *= 0.5
     np.testing.assert_array_equal(P.host_bvh_trace(flat, rays)[0], O.intersect(lightless(O, P, flat), rays))
+
+
+def test_reference_presplitting_keeps_the_contract(P, O, tmp_path):
+    """PTAMD_BVH_SPLIT_ALPHA (off by default: it did not pay on indoor) represents huge faces
+    by several clipped references of the SAME triangle record; results must not change."""
+    import subprocess
+    import sys
+    code = f"""
+import sys, numpy as np
+sys.path[:0] = [{os.path.dirname(ASSETS)!r}, {os.path.join(os.path.dirname(ASSETS), 'oracle')!r}, {os.path.join(os.path.dirname(ASSETS), 'tests')!r}]
+import cuda_pathtracer_amd as P, pt_oracle as O
+from helpers import random_rays
+hs = P.HostScene.load({os.path.join(ASSETS, 'indoor.scene')!r})
+rays = random_rays(np.random.default_rng(5), 20000, 3.4)
+sc = O.OracleScene(hs.faces, hs.mesh_sizes, hs.materials, hs.lights[:0], hs.textures, hs.texels, P.cubemap_from_color())
+got, nodes, tris = P.host_bvh_trace(hs, rays)
+assert (got == O.intersect(sc, rays)).all()
+print(nodes, tris)
+"""
+    base = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
+    env = dict(os.environ, PTAMD_BVH_SPLIT_ALPHA="0.01", PTAMD_BVH_SPLIT_BUDGET="200")
+    split = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=env).stdout.split()
+    assert base != split          # the knob did change the tree
