@@ -43,6 +43,9 @@ namespace ptamd {
 #ifndef PT_PERSISTENT_THREADS
 #define PT_PERSISTENT_THREADS 512
 #endif
+#ifndef PT_ASM_WALK
+#define PT_ASM_WALK 1
+#endif
 #define PT_MAX_DIST 100000.0f
 #define PT_END 0xFFFFFFFFu
 
@@ -162,6 +165,84 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
   w.node = node;
 }
 
+// The same loop for LDS-resident nodes, hand-scheduled.  hipcc's version of the C++ loop above
+// carries ~20 SALU exec-mask instructions per iteration (two exits, phi merges of masks) next to
+// ~35 VALU, and the rocprofv3 counters show 39 % of wave time stalled at issue.  This version
+// keeps one exec update per iteration: lanes leave the loop by clearing their exec bit when they
+// reach a leaf they hit or run off the tree.  v64..v77 are scratch (clobbered); masks live in
+// compiler-allocated SGPR pairs.  Hazards: a VALU that reads an SGPR mask written by a VALU
+// compare needs 2 wait states (s_nop 1), exactly as hipcc pads it; SALU consumers are interlocked.
+PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count)
+{
+  uint32_t node = w.node, first, count;
+  const uint32_t lnk = lds_nodes + w.link_off * 4u; // byte address of this octant's link in node 0
+  unsigned long long save, m_a, m_b, m_int, m_leaf;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "v_mov_b32 %[first], 0\n\t"
+      "v_mov_b32 %[count], 0\n\t"
+      "v_cmp_ne_u32 vcc, -1, %[node]\n\t"
+      "s_and_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execz 2f\n\t"
+      "1:\n\t"
+      "v_lshlrev_b32 v73, 6, %[node]\n\t"
+      "v_add_u32 v77, v73, %[lnk]\n\t"
+      "v_add_u32 v73, v73, %[base]\n\t"
+      "ds_read_b128 v[64:67], v73\n\t"
+      "ds_read_b128 v[68:71], v73 offset:16\n\t"
+      "ds_read_b32 v72, v77\n\t"
+      "v_add_u32 v77, 1, %[node]\n\t"                 // left child = node + 1
+      "s_waitcnt lgkmcnt(1)\n\t"
+      "v_fma_f32 v64, v64, %[ix], %[nx]\n\t"
+      "v_fma_f32 v68, v68, %[ix], %[nx]\n\t"
+      "v_fma_f32 v65, v65, %[iy], %[ny]\n\t"
+      "v_fma_f32 v69, v69, %[iy], %[ny]\n\t"
+      "v_fma_f32 v66, v66, %[iz], %[nz]\n\t"
+      "v_fma_f32 v70, v70, %[iz], %[nz]\n\t"
+      "v_min_f32 v74, v64, v68\n\t"
+      "v_max_f32 v64, v64, v68\n\t"
+      "v_min_f32 v75, v65, v69\n\t"
+      "v_max_f32 v65, v65, v69\n\t"
+      "v_min_f32 v76, v66, v70\n\t"
+      "v_max_f32 v66, v66, v70\n\t"
+      "v_max3_f32 v74, v74, v75, v76\n\t"             // tnear
+      "v_min3_f32 v75, v64, v65, v66\n\t"             // tfar
+      "v_cmp_le_f32 vcc, v74, v75\n\t"
+      "v_cmp_le_f32 %[ma], 0, v75\n\t"
+      "v_cmp_le_f32 %[mb], v74, %[best]\n\t"
+      "v_lshrrev_b32 v76, 24, v67\n\t"                // count
+      "v_lshrrev_b32 v64, 30, v71\n\t"                // split axis
+      "v_and_b32 v65, 0x3fffffff, v71\n\t"            // right child
+      "v_bfe_u32 v64, %[oct], v64, 1\n\t"             // ray goes negative along the axis?
+      "s_and_b64 vcc, vcc, %[ma]\n\t"
+      "s_and_b64 vcc, vcc, %[mb]\n\t"                 // vcc = box hit
+      "v_cmp_eq_u32 %[mint], 0, v76\n\t"              // interior node
+      "v_cmp_ne_u32 %[ma], 0, v64\n\t"
+      "v_and_b32 v66, 0xffffff, v67\n\t"              // first triangle of a leaf
+      "s_andn2_b64 %[mleaf], vcc, %[mint]\n\t"        // hit & leaf
+      "s_and_b64 %[mint], vcc, %[mint]\n\t"           // hit & interior
+      "v_cndmask_b32 v77, v77, v65, %[ma]\n\t"        // near child (2 wait states after the v_cmp: 4 instrs above)
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cndmask_b32 %[node], v72, v77, %[mint]\n\t"  // next = hit interior ? near child : miss link
+      "v_cndmask_b32 %[first], %[first], v66, %[mleaf]\n\t"
+      "v_cndmask_b32 %[count], %[count], v76, %[mleaf]\n\t"
+      "v_cmp_ne_u32 vcc, -1, %[node]\n\t"
+      "s_andn2_b64 vcc, vcc, %[mleaf]\n\t"            // keep walking: not at a hit leaf and not off the tree
+      "s_and_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execnz 1b\n\t"
+      "2:\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      : [node] "+v"(node), [first] "=&v"(first), [count] "=&v"(count), [save] "=&s"(save), [ma] "=&s"(m_a),
+        [mb] "=&s"(m_b), [mint] "=&s"(m_int), [mleaf] "=&s"(m_leaf)
+      : [lnk] "v"(lnk), [base] "v"(lds_nodes), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
+        [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t), [oct] "v"(w.oct)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "vcc",
+        "scc", "memory");
+  leaf_first = first;
+  leaf_count = count;
+  w.node = node;
+}
+
 template <bool STATS>
 PT_DEV void walk_leaf(const float4* tris, Walk& w, uint32_t leaf_first, uint32_t leaf_count, uint32_t& n_tris,
                       uint32_t& wave_tri_iters)
@@ -179,16 +260,19 @@ PT_DEV void walk_leaf(const float4* tris, Walk& w, uint32_t leaf_first, uint32_t
 
 // "while-while": all lanes walk boxes until each holds a leaf (or is done), then all lanes run
 // Moller-Trumbore on their leaf, repeat.
-template <bool STATS>
+template <bool STATS, bool NODES_IN_LDS = false>
 PT_DEV void traverse_bvh(const float4* nodes, const float4* tris, uint32_t n_nodes, f3 o, f3 d,
                          Best& best, uint32_t& n_nodes_visited, uint32_t& n_tris, uint32_t& wave_node_iters,
                          uint32_t& wave_tri_iters)
 {
   Walk w;
   walk_init(w, o, d, n_nodes);
+  // LDS byte address of the node table (low 32 bits of the flat address of an LDS object)
+  const uint32_t lds_nodes = (uint32_t)(uintptr_t)nodes;
   for (;;) {
     uint32_t leaf_first, leaf_count;
-    walk_to_leaf<STATS>(nodes, w, leaf_first, leaf_count, n_nodes_visited, wave_node_iters);
+    if (NODES_IN_LDS && !STATS && PT_ASM_WALK) walk_to_leaf_lds(lds_nodes, w, leaf_first, leaf_count);
+    else walk_to_leaf<STATS>(nodes, w, leaf_first, leaf_count, n_nodes_visited, wave_node_iters);
     if (leaf_count == 0) break;
     walk_leaf<STATS>(tris, w, leaf_first, leaf_count, n_tris, wave_tri_iters);
   }
@@ -241,7 +325,7 @@ PT_DEV Nearest nearest_lights(const KParams& p, f3 o, f3 d, Nearest n)
 
 // First half of intersection.cuh:161-246: the two search loops (faces :179-196, lights :199-212).
 // KIND: 1 brute force, 2 BVH.
-template <int KIND, bool STATS>
+template <int KIND, bool STATS, bool NODES_IN_LDS = false>
 PT_DEV Nearest trace_nearest(const KParams& p, const float4* s_nodes, const float4* s_tris, f3 o, f3 d,
                              Counters& cnt)
 {
@@ -249,7 +333,7 @@ PT_DEV Nearest trace_nearest(const KParams& p, const float4* s_nodes, const floa
   best.t = PT_MAX_DIST; best.u = 0.f; best.v = 0.f; best.idx = PT_END;
   if (STATS) cnt.rays++;
   if (KIND == 1) traverse_brute<STATS>(s_tris, p.n_faces, o, d, best, cnt.tris);
-  else traverse_bvh<STATS>(s_nodes, s_tris, p.n_nodes, o, d, best, cnt.nodes, cnt.tris, cnt.wave_node_iters, cnt.wave_tri_iters);
+  else traverse_bvh<STATS, NODES_IN_LDS>(s_nodes, s_tris, p.n_nodes, o, d, best, cnt.nodes, cnt.tris, cnt.wave_node_iters, cnt.wave_tri_iters);
   Nearest n;
   n.t = best.t; n.u = best.u; n.v = best.v; n.idx = best.idx;
   return nearest_lights(p, o, d, n);
@@ -538,11 +622,11 @@ PT_DEV void stage_to_lds(float4* dst, const float4* src, uint32_t n16)
 }
 
 // The unsplit form used when a lane traces its own ray.
-template <int KIND, bool STATS>
+template <int KIND, bool STATS, bool NODES_IN_LDS = false>
 PT_DEV bool path_step(const KParams& p, const float4* s_nodes, const float4* s_tris, Path& st, Counters& cnt)
 {
   const float r1 = path_pre(p, st);
-  const Nearest n = trace_nearest<KIND, STATS>(p, s_nodes, s_tris, st.o, st.d, cnt);
+  const Nearest n = trace_nearest<KIND, STATS, NODES_IN_LDS>(p, s_nodes, s_tris, st.o, st.d, cnt);
   return path_post<STATS>(p, st, r1, n, cnt);
 }
 
@@ -635,7 +719,7 @@ __global__ void __launch_bounds__(BLOCK, PT_TILE_WAVES_PER_EU) pt_megakernel(con
   if (active) {
     Path st;
     path_begin(p, x, y, st);
-    while (!path_step<KIND, STATS>(p, s_nodes, s_tris, st, cnt)) {}
+    while (!path_step<KIND, STATS, LDS_RESIDENT>(p, s_nodes, s_tris, st, cnt)) {}
     path_finish(p, st);
   }
   flush_counters<STATS>(p, cnt, active ? 1u : 0u);
@@ -728,7 +812,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
       }
     }
     if (__ballot(!idle) == 0ull) break;
-    if (!idle) idle = path_step<KIND, STATS>(p, s_nodes, s_tris, st, cnt);
+    if (!idle) idle = path_step<KIND, STATS, LDS_RESIDENT>(p, s_nodes, s_tris, st, cnt);
   }
   flush_counters<STATS>(p, cnt, samples);
 }
