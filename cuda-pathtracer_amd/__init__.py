@@ -14,5 +14,6 @@ from .render import (Context, FrameRenderer, host_bvh_trace, wang_hash, REFERENC
                      POST_NONE, POST_GRAYSCALE, POST_SEPIA, POST_INVERT)
 from .tiles import row_bands, band_of_rank, BandGather
 from .synthetic import tessellate
+from .image import save_ppm, load_ppm
 
 __all__ = [n for n in dir() if not n.startswith("_")]

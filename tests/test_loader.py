@@ -171,3 +171,11 @@ def test_cubemap_helpers(P):
     # the reference always ends at the default colour when the image cannot be loaded
     hs = P.HostScene.load(os.path.join(ASSETS, "indoor.scene"))
     np.testing.assert_array_equal(P.cubemap_for_scene(hs), c)
+
+
+def test_ppm_roundtrip(P, tmp_path):
+    img = (np.arange(5 * 7 * 4) % 256).astype(np.uint8).reshape(5, 7, 4)
+    P.save_ppm(str(tmp_path / "x.ppm"), img)
+    np.testing.assert_array_equal(P.load_ppm(str(tmp_path / "x.ppm")), img[:, :, :3])
+    with pytest.raises(ValueError):
+        P.save_ppm(str(tmp_path / "y.ppm"), img.astype(np.float32))
