@@ -23,7 +23,14 @@ struct HostScene {
   std::string cubemap;
 };
 
-int load_host_scene(const char* scene_path, uint32_t flags, HostScene*& out);
+// Image decoding is injected by the host application (the role stb_image plays for the reference).
+struct ImageProvider {
+  ptamd_image_load_fn load;
+  ptamd_image_free_fn release;
+  void* user;
+};
+
+int load_host_scene(const char* scene_path, uint32_t flags, const ImageProvider* provider, HostScene*& out);
 
 // ---- BVH (bvh_builder.cpp) -----------------------------------------------------------
 //

@@ -11,10 +11,11 @@
 //   Face flattening ....... scene.cpp:218-262 (AoS Face, per-face tangent)
 //   Materials/textures .... material_loader.cpp:164-401 (diffuse rgb + specular a packed
 //                           into one RGBA float texture, 1x1 fallbacks, global texture ids)
-// Image decoding is not available in this build (no stb in the image, none vendored yet):
-// every texture file is treated as "failed to load", which is exactly what happens to
-// indoor.mtl's backslash paths in the reference on Linux (material_loader.cpp:97-104).
-// This is written from scratch; nothing here is taken from tinyobjloader.
+// Image DECODING is injected by the caller (ptamd_host_scene_load_ex), as stb_image is a vendored
+// third party for the reference; without a provider every texture file "fails to load", which is
+// exactly what happens to indoor.mtl's backslash paths in the reference on Linux
+// (material_loader.cpp:97-104).  This is written from scratch; nothing here is taken from
+// tinyobjloader or stb.
 #include "ptamd_internal.h"
 
 #include <cmath>
@@ -343,31 +344,146 @@ bool load_obj(const std::string& path, const std::string& mtl_dir, ObjData& obj,
 
 } // namespace
 
-// material_loader.cpp:164-197 with every image load failing (see file header): the
-// diffuse+specular texture is always the 1x1 RGBA fallback, the normal map is -1.
-static void build_materials(const ObjData& obj, HostScene& hs)
+// ---------------------------------------------------------------- materials and textures
+//
+// material_loader.cpp:164-401.  Image decoding is injected (ImageProvider): the reference gets
+// its float texels from stb_image's stbi_loadf (material_loader.cpp:97), a host application
+// passes an equivalent through ptamd_host_scene_load_ex.  Without a provider every image "fails
+// to load", which is what the reference does with indoor.mtl's backslash paths on Linux.
+
+namespace {
+
+struct Image { int w = 0, h = 0, nb_chan = 0; std::vector<float> data; }; // nb_chan == 0: not loaded
+
+struct TextureBook {
+  const ImageProvider* provider = nullptr;
+  std::string folder;
+  bool fix_backslashes = false;
+  std::map<std::string, Image> loaded;    // MaterialLoader::_loaded_tex
+  std::map<std::string, int> packed;      // MaterialLoader::_packed_tex
+  HostScene* hs = nullptr;
+
+  int push_texture(int w, int h, int nb_chan, const float* data)
+  {
+    ptamd_texture_desc td{};
+    td.w = w; td.h = h; td.nb_chan = nb_chan;
+    td.offset = hs->texels.size();
+    hs->texels.insert(hs->texels.end(), data, data + (size_t)w * h * nb_chan);
+    hs->textures.push_back(td);
+    return (int)hs->textures.size() - 1; // == MaterialLoader::_id++
+  }
+
+  int push_unit(const float rgba[4], int nb_chan) { return push_texture(1, 1, nb_chan, rgba); }
+
+  // checkAndupload (material_loader.cpp:83-115)
+  const Image& load(const std::string& name)
+  {
+    auto it = loaded.find(name);
+    if (it != loaded.end()) return it->second;
+    Image img;
+    if (provider && provider->load) {
+      std::string rel = name;
+      if (fix_backslashes) for (char& c : rel) if (c == '\\') c = '/';
+      const std::string full = folder + "/" + rel;
+      int32_t w = 0, h = 0, c = 0;
+      float* data = nullptr;
+      if (provider->load(provider->user, full.c_str(), &w, &h, &c, &data) == 0 && data && w > 0 && h > 0 && c > 0) {
+        img.w = w; img.h = h; img.nb_chan = c;
+        img.data.assign(data, data + (size_t)w * h * c);
+      }
+      if (data && provider->release) provider->release(provider->user, data);
+    }
+    if (img.nb_chan == 0) hs->unloaded_textures.push_back(name);
+    return loaded.emplace(name, std::move(img)).first->second;
+  }
+
+  // pack(rgb, a) / pack(tex, default) (material_loader.cpp:15-74)
+  int push_packed(const Image* rgb, const Image* a, const float default_rgb[3], float default_a)
+  {
+    const Image& ref = rgb ? *rgb : *a;
+    std::vector<float> out((size_t)ref.w * ref.h * 4);
+    for (size_t i = 0; i < (size_t)ref.w * ref.h; ++i) {
+      out[i * 4 + 0] = rgb ? rgb->data[i * 3 + 0] : default_rgb[0];
+      out[i * 4 + 1] = rgb ? rgb->data[i * 3 + 1] : default_rgb[1];
+      out[i * 4 + 2] = rgb ? rgb->data[i * 3 + 2] : default_rgb[2];
+      out[i * 4 + 3] = a ? a->data[i] : default_a;
+    }
+    return push_texture(ref.w, ref.h, 4, out.data());
+  }
+
+  // getTextureId(tex_rgb, tex_a, default_rgb, default_a) (material_loader.cpp:243-382)
+  int diffuse_spec(const std::string& tex_rgb, const std::string& tex_a, const float default_rgb[3], float default_a)
+  {
+    const float unit[4] = { default_rgb[0], default_rgb[1], default_rgb[2], default_a };
+    if (tex_rgb.empty() && tex_a.empty()) return push_unit(unit, 4);          // CASE 1
+    const Image* rgb = tex_rgb.empty() ? nullptr : &load(tex_rgb);
+    const Image* a = tex_a.empty() ? nullptr : &load(tex_a);
+    if (!rgb) return a->nb_chan == 1 ? push_packed(nullptr, a, default_rgb, default_a) : push_unit(unit, 4); // CASE 2
+    if (!a) return rgb->nb_chan == 3 ? push_packed(rgb, nullptr, default_rgb, default_a) : push_unit(unit, 4);
+    const std::string token = tex_rgb + tex_a;                                // CASE 3
+    auto it = packed.find(token);
+    if (it != packed.end()) return it->second;
+    if (rgb->nb_chan != 3 && a->nb_chan != 1) return push_unit(unit, 4);      // both failed: not cached (ref. :315-322)
+    int id;
+    if (rgb->nb_chan != 3) id = push_packed(nullptr, a, default_rgb, default_a);
+    else if (a->nb_chan != 1) id = push_packed(rgb, nullptr, default_rgb, default_a);
+    else if (rgb->w == a->w && rgb->h == a->h) id = push_packed(rgb, a, default_rgb, default_a);
+    else {
+      // The reference rescales the smaller map with stb_image_resize (material_loader.cpp:350-375);
+      // that filter is not restated here: the smaller map is resampled with nearest texels.
+      const bool a_bigger = (long)a->w * a->h > (long)rgb->w * rgb->h;
+      const Image& big = a_bigger ? *a : *rgb;
+      const Image& small = a_bigger ? *rgb : *a;
+      Image scaled;
+      scaled.w = big.w; scaled.h = big.h; scaled.nb_chan = small.nb_chan;
+      scaled.data.resize((size_t)big.w * big.h * small.nb_chan);
+      for (int y = 0; y < big.h; ++y)
+        for (int x = 0; x < big.w; ++x) {
+          const int sx = (int)((long)x * small.w / big.w), sy = (int)((long)y * small.h / big.h);
+          for (int c = 0; c < small.nb_chan; ++c)
+            scaled.data[((size_t)y * big.w + x) * small.nb_chan + c] = small.data[((size_t)sy * small.w + sx) * small.nb_chan + c];
+        }
+      id = a_bigger ? push_packed(&scaled, a, default_rgb, default_a) : push_packed(rgb, &scaled, default_rgb, default_a);
+    }
+    packed[token] = id;
+    return id;
+  }
+
+  // getTextureId(tex_rgb) -> registerOrGet (material_loader.cpp:223-230,384-401)
+  int normal_map(const std::string& name)
+  {
+    if (name.empty()) return -1;
+    auto it = packed.find(name);
+    if (it != packed.end()) return it->second;
+    const Image& img = load(name);
+    if (img.nb_chan == 0) return -1;
+    // sampleTexture reads three consecutive floats (intersection.cuh:35-45): a map with fewer than
+    // three channels would be read out of bounds by the reference; it is dropped instead.
+    if (img.nb_chan < 3) return -1;
+    const int id = push_texture(img.w, img.h, img.nb_chan, img.data.data());
+    packed[name] = id;
+    return id;
+  }
+};
+
+} // namespace
+
+static void build_materials(const ObjData& obj, HostScene& hs, const ImageProvider* provider,
+                            const std::string& mtl_folder, bool fix_backslashes)
 {
+  TextureBook book;
+  book.provider = provider;
+  book.folder = mtl_folder;
+  book.fix_backslashes = fix_backslashes;
+  book.hs = &hs;
   for (const MtlEntry& m : obj.materials) {
     ptamd_material mat{};
-    float default_spec = (float)(((double)(m.specular[0] + m.specular[1] + m.specular[2])) / 3.0);
-    // CASE 1 (no names) and the "load failed" arms of CASE 2/3 all push the same unit texture
-    ptamd_texture_desc td{};
-    td.w = 1; td.h = 1; td.nb_chan = 4;
-    td.offset = hs.texels.size();
-    hs.texels.push_back(m.diffuse[0]);
-    hs.texels.push_back(m.diffuse[1]);
-    hs.texels.push_back(m.diffuse[2]);
-    hs.texels.push_back(default_spec);
-    mat.diffuse_spec_map = (int32_t)hs.textures.size();
-    hs.textures.push_back(td);
-    // registerOrGet (material_loader.cpp:384-401): a failed load yields -1 and no id is consumed
-    mat.normal_map = -1;
+    const float default_rgb[3] = { m.diffuse[0], m.diffuse[1], m.diffuse[2] };
+    const float default_spec = (float)(((double)(m.specular[0] + m.specular[1] + m.specular[2])) / 3.0);
+    mat.diffuse_spec_map = book.diffuse_spec(m.diffuse_tex, m.specular_tex, default_rgb, default_spec);
+    mat.normal_map = book.normal_map(!m.bump_tex.empty() ? m.bump_tex : m.normal_tex);
     mat.ior = m.ior;
     hs.materials.push_back(mat);
-    const std::string& nm = !m.bump_tex.empty() ? m.bump_tex : m.normal_tex;
-    if (!m.diffuse_tex.empty()) hs.unloaded_textures.push_back(m.diffuse_tex);
-    if (!m.specular_tex.empty()) hs.unloaded_textures.push_back(m.specular_tex);
-    if (!nm.empty()) hs.unloaded_textures.push_back(nm);
   }
 }
 
@@ -410,9 +526,8 @@ static bool build_faces(const ObjData& obj, HostScene& hs, std::string& err)
   return true;
 }
 
-int load_host_scene(const char* scene_path, uint32_t flags, HostScene*& out)
+int load_host_scene(const char* scene_path, uint32_t flags, const ImageProvider* provider, HostScene*& out)
 {
-  (void)flags; // bit 0 only matters once image decoding exists
   std::ifstream file(scene_path);
   if (!file.is_open()) {
     set_error(std::string("cannot open scene file '") + scene_path + "'");
@@ -476,7 +591,7 @@ int load_host_scene(const char* scene_path, uint32_t flags, HostScene*& out)
     delete hs;
     return PTAMD_ERR_IO;
   }
-  build_materials(obj, *hs);
+  build_materials(obj, *hs, provider, mtl_dir, (flags & 1u) != 0);
   if (!build_faces(obj, *hs, err)) {
     set_error("scene '" + path + "': " + err);
     delete hs;
@@ -496,10 +611,34 @@ int ptamd_host_scene_load(const char* scene_path, uint32_t flags, ptamd_host_sce
 {
   if (!scene_path || !out) { ptamd::set_error("ptamd_host_scene_load: null argument"); return PTAMD_ERR_ARG; }
   ptamd::HostScene* hs = nullptr;
-  int rc = ptamd::load_host_scene(scene_path, flags, hs);
+  int rc = ptamd::load_host_scene(scene_path, flags, nullptr, hs);
   if (rc != PTAMD_OK) return rc;
   *out = reinterpret_cast<ptamd_host_scene*>(hs);
   return PTAMD_OK;
+}
+
+int ptamd_host_scene_load_ex(const char* scene_path, uint32_t flags, ptamd_image_load_fn load, ptamd_image_free_fn release,
+                             void* user, ptamd_host_scene** out)
+{
+  if (!scene_path || !out) { ptamd::set_error("ptamd_host_scene_load_ex: null argument"); return PTAMD_ERR_ARG; }
+  ptamd::ImageProvider prov{ load, release, user };
+  ptamd::HostScene* hs = nullptr;
+  int rc = ptamd::load_host_scene(scene_path, flags, load ? &prov : nullptr, hs);
+  if (rc != PTAMD_OK) return rc;
+  *out = reinterpret_cast<ptamd_host_scene*>(hs);
+  return PTAMD_OK;
+}
+
+uint32_t ptamd_host_scene_unloaded_count(const ptamd_host_scene* s)
+{
+  return s ? (uint32_t)reinterpret_cast<const ptamd::HostScene*>(s)->unloaded_textures.size() : 0u;
+}
+
+const char* ptamd_host_scene_unloaded_name(const ptamd_host_scene* s, uint32_t i)
+{
+  if (!s) return "";
+  const auto& v = reinterpret_cast<const ptamd::HostScene*>(s)->unloaded_textures;
+  return i < v.size() ? v[i].c_str() : "";
 }
 
 void ptamd_host_scene_free(ptamd_host_scene* s) { delete reinterpret_cast<ptamd::HostScene*>(s); }

@@ -86,11 +86,19 @@ class SceneInfo(C.Structure):
 
 assert C.sizeof(Face) == 112 and C.sizeof(Material) == 16 and C.sizeof(Light) == 32 and C.sizeof(Camera) == 64
 
+IMAGE_LOAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                            C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_float)))
+IMAGE_FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float))
+
 # name -> (restype, argtypes); every symbol include/ptamd.h declares
 SIGNATURES = {
     "ptamd_get_last_error": (C.c_char_p, []),
     "ptamd_version": (C.c_char_p, []),
     "ptamd_host_scene_load": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ptamd_host_scene_load_ex": (C.c_int, [C.c_char_p, C.c_uint32, IMAGE_LOAD_FN, IMAGE_FREE_FN, C.c_void_p,
+                                            C.POINTER(C.c_void_p)]),
+    "ptamd_host_scene_unloaded_count": (C.c_uint32, [C.c_void_p]),
+    "ptamd_host_scene_unloaded_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "ptamd_host_scene_free": (None, [C.c_void_p]),
     "ptamd_host_scene_desc": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "ptamd_host_scene_camera": (C.c_int, [C.c_void_p, C.POINTER(Camera)]),

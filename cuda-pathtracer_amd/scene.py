@@ -35,7 +35,9 @@ def _copy_array(ptr, count, dtype):
 class HostScene:
     """Flattened scene + initial camera + cubemap name (scene::Scene's host state)."""
 
-    def __init__(self, faces, mesh_sizes, materials, lights, textures, texels, camera=None, cubemap=""):
+    def __init__(self, faces, mesh_sizes, materials, lights, textures, texels, camera=None, cubemap="",
+                 unloaded_textures=()):
+        self.unloaded_textures = list(unloaded_textures)
         self.faces = np.ascontiguousarray(faces, dtype=FACE_DTYPE)
         self.mesh_sizes = np.ascontiguousarray(mesh_sizes, dtype=np.uint32)
         self.materials = np.ascontiguousarray(materials, dtype=MATERIAL_DTYPE)
@@ -46,11 +48,40 @@ class HostScene:
         self.cubemap = cubemap
 
     @classmethod
-    def load(cls, scene_path: str, normalise_backslashes: bool = False) -> "HostScene":
-        """Parses a .scene file and the OBJ/MTL it names (ptamd_host_scene_load)."""
+    def load(cls, scene_path: str, normalise_backslashes: bool = False, image_loader=None) -> "HostScene":
+        """Parses a .scene file and the OBJ/MTL it names (ptamd_host_scene_load[_ex]).
+
+        image_loader: optional `f(path) -> float32[h, w, c] | None` with stbi_loadf semantics (see
+        images.pil_image_loader).  Without it every texture file "fails to load" (1x1 fallbacks)."""
         lib = N.load()
         h = C.c_void_p()
-        N.check(lib.ptamd_host_scene_load(scene_path.encode(), 1 if normalise_backslashes else 0, C.byref(h)))
+        flags = 1 if normalise_backslashes else 0
+        if image_loader is None:
+            N.check(lib.ptamd_host_scene_load(scene_path.encode(), flags, C.byref(h)))
+        else:
+            keep = {}
+
+            def _load(user, path, pw, ph, pc, pdata):
+                try:
+                    img = image_loader(path.decode())
+                except Exception:
+                    img = None
+                if img is None:
+                    return 1
+                img = np.ascontiguousarray(img, dtype=np.float32)
+                if img.ndim == 2:
+                    img = img[:, :, None]
+                buf = (C.c_float * img.size).from_buffer_copy(img.tobytes())
+                keep[C.addressof(buf)] = buf
+                pw[0], ph[0], pc[0] = img.shape[1], img.shape[0], img.shape[2]
+                pdata[0] = C.cast(buf, C.POINTER(C.c_float))
+                return 0
+
+            def _free(user, data):
+                keep.pop(C.cast(data, C.c_void_p).value, None)
+
+            cb_load, cb_free = N.IMAGE_LOAD_FN(_load), N.IMAGE_FREE_FN(_free)
+            N.check(lib.ptamd_host_scene_load_ex(scene_path.encode(), flags, cb_load, cb_free, None, C.byref(h)))
         try:
             d = N.SceneDesc()
             N.check(lib.ptamd_host_scene_desc(h, C.byref(d)))
@@ -58,13 +89,15 @@ class HostScene:
             N.check(lib.ptamd_host_scene_camera(h, C.byref(cam)))
             camera = np.frombuffer(bytes(cam), dtype=CAMERA_DTYPE)[0].copy()
             cubemap = lib.ptamd_host_scene_cubemap(h).decode()
+            unloaded = [lib.ptamd_host_scene_unloaded_name(h, i).decode()
+                        for i in range(lib.ptamd_host_scene_unloaded_count(h))]
             return cls(_copy_array(d.faces, d.n_faces, FACE_DTYPE),
                        _copy_array(d.mesh_sizes, d.n_meshes, np.dtype("<u4")),
                        _copy_array(d.materials, d.n_materials, MATERIAL_DTYPE),
                        _copy_array(d.lights, d.n_lights, LIGHT_DTYPE),
                        _copy_array(d.textures, d.n_textures, TEXTURE_DTYPE),
                        _copy_array(d.texels, d.n_texel_floats, np.dtype("<f4")),
-                       camera, cubemap)
+                       camera, cubemap, unloaded)
         finally:
             lib.ptamd_host_scene_free(h)
 
@@ -107,15 +140,25 @@ def cubemap_from_cross(cross: np.ndarray) -> np.ndarray:
     return out.reshape(6, osz.value, osz.value, 4)
 
 
-def cubemap_for_scene(scene: HostScene, honour_hex: bool = False) -> np.ndarray:
-    """The cubemap the reference binds for this scene when the image cannot be loaded.
+def cubemap_for_scene(scene: HostScene, honour_hex: bool = False, asset_folder: str = None,
+                      image_loader=None) -> np.ndarray:
+    """The cubemap the reference binds for this scene (gpu_processor.cpp:68-161).
 
-    uploadCubemaps passes `folder + "/" + name` to uploadCubemap (gpu_processor.cpp:177-181),
-    so the `path.empty() || isHexa(path)` arm (:89-93) is never taken: a `0xRRGGBB` name, a
-    missing file (indoor.scene's garden.jpg) and no name at all all end in the 1x1 fallback
-    of colour 0x131b23 (:128-132).  `honour_hex=True` applies the constant syntax as its
-    author evidently intended (not reference behaviour)."""
+    With `asset_folder` and `image_loader` the cube-cross image `folder/name` is decoded and cut
+    into six faces when it is a valid cross (width/4 == height/3, power of two); any failure —
+    as for indoor.scene's missing garden.jpg — ends in the 1x1 fallback of colour 0x131b23
+    (:128-132).  uploadCubemaps passes `folder + "/" + name` to uploadCubemap (:177-181), so the
+    `path.empty() || isHexa(path)` arm (:89-93) is never taken by the reference: a `0xRRGGBB`
+    name also ends in the fallback.  `honour_hex=True` applies the constant syntax as its author
+    evidently intended (not reference behaviour)."""
     name = scene.cubemap
     if honour_hex and name.startswith("0x") and len(name) > 2 and all(ch in "0123456789abcdefABCDEF" for ch in name[2:]):
         return cubemap_from_color(int(name, 16) & 0xFFFFFF)
+    if asset_folder is not None and image_loader is not None and name:
+        try:
+            img = image_loader(asset_folder + "/" + name)
+            if img is not None:
+                return cubemap_from_cross(img)
+        except (N.PtamdError, OSError, ValueError):
+            pass
     return cubemap_from_color(DEFAULT_CUBEMAP_COLOR)

@@ -115,6 +115,20 @@ typedef struct ptamd_host_scene ptamd_host_scene;
  * in MTL texture paths (default 0 = reference-on-Linux behaviour: such textures fail to
  * load and degrade to 1x1 constants, material_loader.cpp:97-104). */
 int  ptamd_host_scene_load(const char* scene_path, uint32_t flags, ptamd_host_scene** out);
+
+/* Image decoding is injected, as stb_image is for the reference (material_loader.cpp:97 stbi_loadf):
+ * `load` returns 0 and a w*h*nb_chan float buffer (already linearised the way stbi_loadf does it:
+ * colour channels pow(v/255, 2.2), alpha v/255) or non-zero when the file cannot be decoded;
+ * `release` frees that buffer.  With load == NULL this is ptamd_host_scene_load.  The loader then
+ * applies material_loader.cpp:243-401 (diffuse rgb + specular a packed into one RGBA texture, 1x1
+ * fallbacks, normal maps registered as they are, de-duplication by name). */
+typedef int (*ptamd_image_load_fn)(void* user, const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, float** data);
+typedef void (*ptamd_image_free_fn)(void* user, float* data);
+int  ptamd_host_scene_load_ex(const char* scene_path, uint32_t flags, ptamd_image_load_fn load,
+                              ptamd_image_free_fn release, void* user, ptamd_host_scene** out);
+/* Names (as written in the MTL) of image files that could not be loaded. */
+uint32_t ptamd_host_scene_unloaded_count(const ptamd_host_scene* s);
+const char* ptamd_host_scene_unloaded_name(const ptamd_host_scene* s, uint32_t i);
 void ptamd_host_scene_free(ptamd_host_scene* s);
 /* Borrowed views into the loaded scene, valid until ptamd_host_scene_free. */
 int  ptamd_host_scene_desc(const ptamd_host_scene* s, ptamd_scene_desc* out);

@@ -301,6 +301,19 @@ def test_config4_sponza_class_deep_bvh(P, O, gpu_ctx, indoor):
     assert np.abs(a0.mean() - b0.mean()) < 0.01
 
 
+def test_crate_land_with_real_textures_and_cubemap(P, O, gpu_ctx):
+    """The reference scene that exercises sampleTexture on 1024^2 RGBA textures, normal mapping and
+    a bilinear 1024^2 cubemap (decoded through the injected image provider)."""
+    hs = P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"), image_loader=P.pil_image_loader)
+    cube = P.cubemap_for_scene(hs, asset_folder=ASSETS, image_loader=P.pil_image_loader)
+    assert cube.shape[1] == 1024 and len(hs.texels) > 14_000_000
+    ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 96, 54, spp=2, bounces=4)
+    assert O.last_stats()["nmap_hits"] > 100
+    for kernel in KERNELS:
+        acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 96, 54, 2, 4, kid(P, kernel))
+        assert_same(acc, rgba, *ref, f"crate_land textured/{kernel}")
+
+
 def test_stats_are_consistent(P, O, gpu_ctx, indoor):
     """Instrumented launch: ray/mesh-hit counts equal the oracle's, BVH tests far fewer triangles."""
     import torch

@@ -179,3 +179,99 @@ def test_ppm_roundtrip(P, tmp_path):
     np.testing.assert_array_equal(P.load_ppm(str(tmp_path / "x.ppm")), img[:, :, :3])
     with pytest.raises(ValueError):
         P.save_ppm(str(tmp_path / "y.ppm"), img.astype(np.float32))
+
+
+def _fake_images():
+    """A tiny image set served through the provider callback: name -> float32[h, w, c]."""
+    rng = np.random.default_rng(1)
+    return {
+        "rgb4x2.img": rng.uniform(0, 1, (2, 4, 3)).astype(np.float32),
+        "a4x2.img": rng.uniform(0, 1, (2, 4, 1)).astype(np.float32),
+        "a2x1.img": rng.uniform(0, 1, (1, 2, 1)).astype(np.float32),
+        "nrm3x3.img": rng.uniform(0, 1, (3, 3, 3)).astype(np.float32),
+        "gray.img": rng.uniform(0, 1, (2, 2, 1)).astype(np.float32),
+        "sub/dir.img": rng.uniform(0, 1, (1, 1, 3)).astype(np.float32),
+    }
+
+
+def test_material_packing_rules_with_image_provider(P, tmp_path):
+    """material_loader.cpp:243-401 through an injected image provider (the role of stbi_loadf)."""
+    imgs = _fake_images()
+    calls = []
+
+    def provider(path):
+        calls.append(path)
+        for k, v in imgs.items():
+            if path.endswith("/" + k):
+                return v
+        return None
+
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\n" +
+                                    "".join(f"usemtl m{i}\nf 1/1/1 2/1/1 3/1/1\n" for i in range(9)))
+    (tmp_path / "m.mtl").write_text(
+        "newmtl m0\nKd 0.1 0.2 0.3\nKs 0.3 0.3 0.3\n"                                        # case 1: no maps
+        "newmtl m1\nKd 0.1 0.2 0.3\nKs 0.6 0.6 0.6\nmap_Kd rgb4x2.img\n"                     # case 2: rgb only
+        "newmtl m2\nKd 0.4 0.5 0.6\nKs 0.9 0.9 0.9\nmap_Ks a4x2.img\n"                       # case 2: a only
+        "newmtl m3\nKd 0.4 0.5 0.6\nKs 0.0 0.0 0.0\nmap_Kd rgb4x2.img\nmap_Ks a4x2.img\nmap_Bump nrm3x3.img\n"  # case 3
+        "newmtl m4\nKd 0.7 0.7 0.7\nKs 0.0 0.0 0.0\nmap_Kd rgb4x2.img\nmap_Ks a4x2.img\nnorm nrm3x3.img\n"      # cached pack + cached normal
+        "newmtl m5\nKd 0.7 0.8 0.9\nKs 0.3 0.3 0.3\nmap_Kd missing.img\nmap_Bump gray.img\n"  # rgb fails -> unit; 1-channel normal dropped
+        "newmtl m6\nKd 0.2 0.2 0.2\nKs 0.5 0.5 0.5\nmap_Kd missing.img\nmap_Ks a4x2.img\n"   # case 3, rgb failed: pack(a, default rgb)
+        "newmtl m7\nKd 0.2 0.2 0.2\nKs 0.5 0.5 0.5\nmap_Kd rgb4x2.img\nmap_Ks a2x1.img\n"    # sizes differ: smaller map resampled
+        "newmtl m8\nKd 0.2 0.2 0.2\nKs 0.5 0.5 0.5\nmap_Kd sub\\dir.img\n")               # backslash path
+    (tmp_path / "m.scene").write_text("scene m.obj\n")
+    hs = P.HostScene.load(str(tmp_path / "m.scene"), image_loader=provider)
+    def tex(i):
+        t = hs.textures[int(i)]
+        o, w, h, c = int(t["offset"]), int(t["w"]), int(t["h"]), int(t["nb_chan"])
+        return hs.texels[o: o + w * h * c].reshape(h, w, c)
+
+    m = hs.materials
+    # m0: 1x1 unit (Kd, mean Ks)
+    np.testing.assert_array_equal(tex(m[0]["diffuse_spec_map"]).ravel(), np.float32([0.1, 0.2, 0.3, np.float32(np.float64(np.float32(0.3) * 3) / 3.0)]))
+    # m1: rgb + default alpha
+    t = tex(m[1]["diffuse_spec_map"])
+    np.testing.assert_array_equal(t[..., :3], imgs["rgb4x2.img"])
+    assert (t[..., 3] == np.float32(np.float64(np.float32(0.6) + np.float32(0.6) + np.float32(0.6)) / 3.0)).all()
+    # m2: default rgb + alpha map
+    t = tex(m[2]["diffuse_spec_map"])
+    np.testing.assert_array_equal(t[..., 3], imgs["a4x2.img"][..., 0])
+    np.testing.assert_array_equal(t[0, 0, :3], np.float32([0.4, 0.5, 0.6]))
+    # m3/m4: packed once, normal map registered once (ids shared), normal stored as 3 channels
+    assert m[3]["diffuse_spec_map"] == m[4]["diffuse_spec_map"] and m[3]["normal_map"] == m[4]["normal_map"] >= 0
+    t = tex(m[3]["diffuse_spec_map"])
+    np.testing.assert_array_equal(t[..., :3], imgs["rgb4x2.img"])
+    np.testing.assert_array_equal(t[..., 3], imgs["a4x2.img"][..., 0])
+    np.testing.assert_array_equal(tex(m[3]["normal_map"]), imgs["nrm3x3.img"])
+    # m5: failed diffuse -> unit; 1-channel "normal map" dropped (the reference would read out of bounds)
+    assert hs.textures[m[5]["diffuse_spec_map"]]["w"] == 1 and m[5]["normal_map"] == -1
+    # m6: rgb failed, alpha present -> alpha map with default rgb
+    t = tex(m[6]["diffuse_spec_map"])
+    assert t.shape == (2, 4, 4) and (t[..., 0] == np.float32(0.2)).all()
+    np.testing.assert_array_equal(t[..., 3], imgs["a4x2.img"][..., 0])
+    # m7: alpha 2x1 brought to 4x2
+    t = tex(m[7]["diffuse_spec_map"])
+    assert t.shape == (2, 4, 4)
+    np.testing.assert_array_equal(t[0, :, 3], np.repeat(imgs["a2x1.img"][0, :, 0], 2))
+    # m8: backslash path fails on Linux unless normalised (SURVEY D6)
+    assert hs.textures[m[8]["diffuse_spec_map"]]["w"] == 1 and "sub\\dir.img" in hs.unloaded_textures and "missing.img" in hs.unloaded_textures
+    hs2 = P.HostScene.load(str(tmp_path / "m.scene"), normalise_backslashes=True, image_loader=provider)
+    o8 = int(hs2.textures[int(hs2.materials[8]["diffuse_spec_map"])]["offset"])
+    np.testing.assert_array_equal(hs2.texels[o8: o8 + 3], imgs["sub/dir.img"].ravel())
+    assert calls.count(str(tmp_path) + "//rgb4x2.img") == 2      # decoded once per scene load (_loaded_tex), two loads
+
+
+def test_ldr_to_float_and_real_assets(P):
+    """stbi_loadf's conversion rule and the shipped crate_land textures / cube cross."""
+    img = np.array([[[0, 128, 255, 64]]], dtype=np.uint8)
+    f = P.ldr_to_float(img)
+    np.testing.assert_allclose(f[0, 0, :3], [0.0, (128 / 255) ** 2.2, 1.0], rtol=1e-6)
+    assert f[0, 0, 3] == np.float32(64) / np.float32(255)          # alpha stays linear
+    assert P.ldr_to_float(np.array([[7]], dtype=np.uint8)).shape == (1, 1, 1)
+    hs = P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"), image_loader=P.pil_image_loader)
+    assert hs.unloaded_textures == []
+    assert [(t["w"], t["h"], t["nb_chan"]) for t in hs.textures] == [(1024, 1024, 4), (1024, 1024, 3)] * 2   # SURVEY §8-c
+    assert list(hs.materials["normal_map"]) == [1, 3]
+    cube = P.cubemap_for_scene(hs, asset_folder=ASSETS, image_loader=P.pil_image_loader)
+    assert cube.shape == (6, 1024, 1024, 4) and (cube[..., 3] == 0).all() and 0.05 < cube[..., :3].mean() < 0.9
+    # without a provider the same scene degrades to constants, like every scene did before
+    assert len(P.HostScene.load(os.path.join(ASSETS, "crate_land.scene")).texels) == 8
