@@ -197,8 +197,10 @@ def main():
         dt = float(t.item())
 
     # kernel time from HIP events on the launch stream (average megakernel launch duration)
-    # batched: one megakernel launch (+ the small resolve kernel) covers all spp frames; quoted per 1-spp frame
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(args.steps, 1) / spp
+    # one launch = `frames_per_launch` 1-spp frames (batched: all spp in one megakernel dispatch + the small
+    # resolve kernel; sequential: one frame)
+    frames_per_launch = spp if batched else 1
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(args.steps, 1) / (spp / frames_per_launch)
 
     # exact traversal counts for the algorithmic-bytes figure (instrumented build, untimed)
     stats = {k: 0 for k in ("rays", "nodes_visited", "tris_tested", "mesh_hits", "nmap_hits", "samples")}
@@ -218,9 +220,9 @@ def main():
     else:
         trav = stats["rays"] * (info["n_faces"] * 36 + n_lights * 32)
     alg_bytes_frame = 28 * stats["samples"] + 16 * stats["mesh_hits"] + 12 * stats["nmap_hits"] + trav
-    alg_bytes_launch = alg_bytes_frame / spp
+    alg_bytes_launch = alg_bytes_frame / spp * frames_per_launch
     achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
-    compulsory_launch = 28 * (y1 - y0) * W + hs.scene_bytes()
+    compulsory_launch = (28 * (y1 - y0) * W) * frames_per_launch + hs.scene_bytes()
 
     checksum = int(fr.surface.to(torch.int64).sum().item())
     samples_total = W * H * spp * args.steps
@@ -232,7 +234,8 @@ def main():
             try:
                 with open(args.traffic_json) as f:
                     tj = json.load(f)
-                if tj.get("kernel") == args.kernel and tj.get("workload") == f"{W}x{H}":
+                if (tj.get("kernel") == args.kernel and tj.get("workload") == f"{W}x{H}" and args.tessellate == 1
+                        and tj.get("frames_per_launch") == frames_per_launch and tj.get("bounces") == B):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -246,12 +249,13 @@ def main():
             "config": {"workload": f"{os.path.basename(args.scene)}" + (f" x{args.tessellate}^2 tessellation" if args.tessellate > 1 else "")
                                    + f" {W}x{H} {spp} spp {B} bounces"
                                    + (f" ({'configs[1]' if world == 1 else 'configs[2]'})" if (W, H, spp, B, args.tessellate, args.aperture) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None) else ""),
-                       "kernel": args.kernel, "launches_per_frame": 1 if batched else spp, "faces": info["n_faces"], "bvh_nodes": info["n_nodes"],
+                       "kernel": args.kernel, "launches_per_frame": 1 if batched else spp, "frames_per_launch": frames_per_launch, "faces": info["n_faces"], "bvh_nodes": info["n_nodes"],
                        "parallelism": f"rows/{world}" + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": {"persistent": "pt_megakernel_persistent", "blockwise": "pt_megakernel_blockwise"}.get(args.kernel, "pt_megakernel"), "kernel_ms_per_launch": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+                         "samples_per_launch": int(stats["samples"] / spp * frames_per_launch),
                          "algorithmic_bytes_per_sample": round(alg_bytes_frame / max(stats["samples"], 1), 1),
                          "compulsory_hbm_bytes_per_launch": int(compulsory_launch),
                          "compulsory_hbm_gbps": round(compulsory_launch / (kern_ms * 1e-3) / 1e9, 2),

@@ -169,7 +169,7 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
 // carries ~20 SALU exec-mask instructions per iteration (two exits, phi merges of masks) next to
 // ~35 VALU, and the rocprofv3 counters show 39 % of wave time stalled at issue.  This version
 // keeps one exec update per iteration: lanes leave the loop by clearing their exec bit when they
-// reach a leaf they hit or run off the tree.  v64..v77 are scratch (clobbered); masks live in
+// reach a leaf they hit or run off the tree.  v64..v74 are scratch (clobbered); masks live in
 // compiler-allocated SGPR pairs.  Hazards: a VALU that reads an SGPR mask written by a VALU
 // compare needs 2 wait states (s_nop 1), exactly as hipcc pads it; SALU consumers are interlocked.
 PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count)
@@ -186,12 +186,12 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
       "s_cbranch_execz 2f\n\t"
       "1:\n\t"
       "v_lshlrev_b32 v73, 6, %[node]\n\t"
-      "v_add_u32 v77, v73, %[lnk]\n\t"
+      "v_add_u32 v74, v73, %[lnk]\n\t"
       "v_add_u32 v73, v73, %[base]\n\t"
-      "ds_read_b128 v[64:67], v73\n\t"
-      "ds_read_b128 v[68:71], v73 offset:16\n\t"
-      "ds_read_b32 v72, v77\n\t"
-      "v_add_u32 v77, 1, %[node]\n\t"                 // left child = node + 1
+      "ds_read_b128 v[64:67], v73\n\t"                 // lo.xyz, leaf info
+      "ds_read_b128 v[68:71], v73 offset:16\n\t"       // hi.xyz, right child | axis
+      "ds_read_b32 v72, v74\n\t"                       // miss link of this ray's octant
+      "v_add_u32 v73, 1, %[node]\n\t"                  // left child = node + 1
       "s_waitcnt lgkmcnt(1)\n\t"
       "v_fma_f32 v64, v64, %[ix], %[nx]\n\t"
       "v_fma_f32 v68, v68, %[ix], %[nx]\n\t"
@@ -201,33 +201,33 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
       "v_fma_f32 v70, v70, %[iz], %[nz]\n\t"
       "v_min_f32 v74, v64, v68\n\t"
       "v_max_f32 v64, v64, v68\n\t"
-      "v_min_f32 v75, v65, v69\n\t"
+      "v_min_f32 v68, v65, v69\n\t"
       "v_max_f32 v65, v65, v69\n\t"
-      "v_min_f32 v76, v66, v70\n\t"
+      "v_min_f32 v69, v66, v70\n\t"
       "v_max_f32 v66, v66, v70\n\t"
-      "v_max3_f32 v74, v74, v75, v76\n\t"             // tnear
-      "v_min3_f32 v75, v64, v65, v66\n\t"             // tfar
-      "v_cmp_le_f32 vcc, v74, v75\n\t"
-      "v_cmp_le_f32 %[ma], 0, v75\n\t"
+      "v_max3_f32 v74, v74, v68, v69\n\t"              // tnear
+      "v_min3_f32 v64, v64, v65, v66\n\t"              // tfar
+      "v_cmp_le_f32 vcc, v74, v64\n\t"
+      "v_cmp_le_f32 %[ma], 0, v64\n\t"
       "v_cmp_le_f32 %[mb], v74, %[best]\n\t"
-      "v_lshrrev_b32 v76, 24, v67\n\t"                // count
-      "v_lshrrev_b32 v64, 30, v71\n\t"                // split axis
-      "v_and_b32 v65, 0x3fffffff, v71\n\t"            // right child
-      "v_bfe_u32 v64, %[oct], v64, 1\n\t"             // ray goes negative along the axis?
+      "v_lshrrev_b32 v68, 24, v67\n\t"                 // count
+      "v_lshrrev_b32 v64, 30, v71\n\t"                 // split axis
+      "v_and_b32 v65, 0x3fffffff, v71\n\t"             // right child
+      "v_bfe_u32 v64, %[oct], v64, 1\n\t"              // ray goes negative along the axis?
       "s_and_b64 vcc, vcc, %[ma]\n\t"
-      "s_and_b64 vcc, vcc, %[mb]\n\t"                 // vcc = box hit
-      "v_cmp_eq_u32 %[mint], 0, v76\n\t"              // interior node
+      "s_and_b64 vcc, vcc, %[mb]\n\t"                  // vcc = box hit
+      "v_cmp_eq_u32 %[mint], 0, v68\n\t"               // interior node
       "v_cmp_ne_u32 %[ma], 0, v64\n\t"
-      "v_and_b32 v66, 0xffffff, v67\n\t"              // first triangle of a leaf
-      "s_andn2_b64 %[mleaf], vcc, %[mint]\n\t"        // hit & leaf
-      "s_and_b64 %[mint], vcc, %[mint]\n\t"           // hit & interior
-      "v_cndmask_b32 v77, v77, v65, %[ma]\n\t"        // near child (2 wait states after the v_cmp: 4 instrs above)
+      "v_and_b32 v66, 0xffffff, v67\n\t"               // first triangle of a leaf
+      "s_andn2_b64 %[mleaf], vcc, %[mint]\n\t"         // hit & leaf
+      "s_and_b64 %[mint], vcc, %[mint]\n\t"            // hit & interior
+      "v_cndmask_b32 v73, v73, v65, %[ma]\n\t"         // near child (2+ wait states after the v_cmp above)
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_cndmask_b32 %[node], v72, v77, %[mint]\n\t"  // next = hit interior ? near child : miss link
+      "v_cndmask_b32 %[node], v72, v73, %[mint]\n\t"   // next = hit interior ? near child : miss link
       "v_cndmask_b32 %[first], %[first], v66, %[mleaf]\n\t"
-      "v_cndmask_b32 %[count], %[count], v76, %[mleaf]\n\t"
+      "v_cndmask_b32 %[count], %[count], v68, %[mleaf]\n\t"
       "v_cmp_ne_u32 vcc, -1, %[node]\n\t"
-      "s_andn2_b64 vcc, vcc, %[mleaf]\n\t"            // keep walking: not at a hit leaf and not off the tree
+      "s_andn2_b64 vcc, vcc, %[mleaf]\n\t"             // keep walking: not at a hit leaf and not off the tree
       "s_and_b64 exec, exec, vcc\n\t"
       "s_cbranch_execnz 1b\n\t"
       "2:\n\t"
@@ -236,8 +236,7 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
         [mb] "=&s"(m_b), [mint] "=&s"(m_int), [mleaf] "=&s"(m_leaf)
       : [lnk] "v"(lnk), [base] "v"(lds_nodes), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
         [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t), [oct] "v"(w.oct)
-      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "vcc",
-        "scc", "memory");
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "vcc", "scc", "memory");
   leaf_first = first;
   leaf_count = count;
   w.node = node;

@@ -16,4 +16,5 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   echo "pass $i ($SET) rc=$?"
 done
 python3 $R/scripts/summarize_pmc.py $OUT $KERNEL > $R/gpurun_out/pmc_summary_$KERNEL.json
-python3 $R/scripts/collect_traffic.py $R/gpurun_out/pmc_summary_$KERNEL.json $KERNEL $R/gpurun_out/traffic_$KERNEL.json
+FPL=1; if [ "$KERNEL" = "persistent" ]; then FPL=4; fi   # bench.py batches the 4 spp of a frame into one persistent launch
+python3 $R/scripts/collect_traffic.py $R/gpurun_out/pmc_summary_$KERNEL.json $KERNEL $R/gpurun_out/traffic_$KERNEL.json $FPL

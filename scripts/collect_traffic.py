@@ -7,9 +7,10 @@ mostly 4-byte-per-lane accumulator gathers, for which the guide says the factor 
 the corrected and the raw figure are recorded."""
 import json, os, sys
 summary, kernel, out = sys.argv[1], sys.argv[2], sys.argv[3]
+frames_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 d = json.load(open(summary))
 fetch_kb, write_kb = d.get("FETCH_SIZE"), d.get("WRITE_SIZE")
-res = {"kernel": kernel, "workload": "1920x1080",
+res = {"kernel": kernel, "workload": "1920x1080", "frames_per_launch": frames_per_launch, "bounces": 4,
        "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
        "hbm_read_bytes_per_launch_corrected_x2": None if fetch_kb is None else fetch_kb * 1024 * 2,
        "hbm_write_bytes_per_launch": None if write_kb is None else write_kb * 1024,
