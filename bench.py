@@ -44,6 +44,11 @@ def parse_args():
     ap.add_argument("--tessellate", type=int, default=1, help="split every face into n*n (24 -> ~257k tris, configs[3])")
     ap.add_argument("--aperture", type=float, default=None, help="override the camera aperture (configs[4]: 0.113)")
     ap.add_argument("--kernel", choices=["persistent", "bvh", "blockwise", "brute"], default="persistent")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames rendered concurrently on separate HIP streams, each with its own context and "
+                         "buffers (double buffering, as the reference double-buffers its GL renderbuffers: "
+                         "driver/interop.cpp:107-111).  0 = auto: 1 on one GPU, 2 on several GPUs so that the "
+                         "RCCL all-gather of frame i overlaps the render of frame i+1")
     ap.add_argument("--sequential", action="store_true", help="one launch per spp instead of one batched launch per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -151,31 +156,43 @@ def main():
     if args.aperture is not None:
         hs.camera["aperture"] = args.aperture
     cube = P.cubemap_for_scene(hs)
-    ctx = P.Context(local_rank)
-    ctx.setup_function_tables()
-    sid = ctx.upload_scene(hs)
-    cid = ctx.upload_cubemap(cube)
-    info = ctx.scene_info(sid)
-
+    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world > 1 else 1)
     dev = torch.device("cuda", local_rank)
-    bg = P.BandGather(H, W, world, rank, dev) if (world > 1 or force_gather) else None
     y0, y1 = P.row_bands(H, world)[rank]
-    fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True)
-    stream = torch.cuda.current_stream()
     batched = (not args.sequential) and args.kernel == "persistent" and spp > 1
+
+    class Slot:
+        """One frame in flight: its own context (ticket counters, sample scratch), buffers and stream."""
+
+        def __init__(self, use_current_stream):
+            self.ctx = P.Context(local_rank)
+            self.ctx.setup_function_tables()
+            self.sid = self.ctx.upload_scene(hs)
+            self.cid = self.ctx.upload_cubemap(cube)
+            self.fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True)
+            self.bg = P.BandGather(H, W, world, rank, dev) if (world > 1 or force_gather) else None
+            self.stream = torch.cuda.current_stream() if use_current_stream else torch.cuda.Stream(device=dev)
+
+    slots = [Slot(n_slots == 1) for _ in range(n_slots)]
+    ctx, sid, cid, fr, bg = slots[0].ctx, slots[0].sid, slots[0].cid, slots[0].fr, slots[0].bg
+    info = ctx.scene_info(sid)
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    counter = [0]
 
     def step(i_timed=None):
-        fr.accum.zero_()
-        if i_timed is not None:
-            ev0[i_timed].record(stream)
-        fr.render(spp=spp, bounces=B, kernel=kernel, stream=stream, batched=batched)
-        if i_timed is not None:
-            ev1[i_timed].record(stream)
-        if bg is not None:
-            bg.gather(fr.surface)  # one RCCL all-gather of the RGBA8 bands per frame
+        sl = slots[counter[0] % n_slots]
+        counter[0] += 1
+        with torch.cuda.stream(sl.stream):
+            sl.fr.accum.zero_()
+            if i_timed is not None:
+                ev0[i_timed].record(sl.stream)
+            sl.fr.render(spp=spp, bounces=B, kernel=kernel, stream=sl.stream, batched=batched)
+            if i_timed is not None:
+                ev1[i_timed].record(sl.stream)
+            if sl.bg is not None:
+                sl.bg.gather(sl.fr.surface)  # one RCCL all-gather of the RGBA8 bands per frame
 
     def barrier():
         if world > 1:
@@ -250,6 +267,7 @@ def main():
                                    + f" {W}x{H} {spp} spp {B} bounces"
                                    + (f" ({'configs[1]' if world == 1 else 'configs[2]'})" if (W, H, spp, B, args.tessellate, args.aperture) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None) else ""),
                        "kernel": args.kernel, "launches_per_frame": 1 if batched else spp, "frames_per_launch": frames_per_launch, "faces": info["n_faces"], "bvh_nodes": info["n_nodes"],
+                       "frames_in_flight": n_slots,
                        "parallelism": f"rows/{world}" + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,

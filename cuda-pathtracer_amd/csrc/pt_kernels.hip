@@ -439,9 +439,12 @@ struct Path {
   f3 o, d, throughput, acc;
   Xorwow rng;
   float specular_col; // carried over between iterations
-  int b;
-  uint32_t x, y;
-  uint32_t k; // sample index inside a batched launch (0 otherwise)
+  uint32_t xy; // pixel: x | y << 16 (frames are at most 65536 wide/high, checked by the API)
+  uint32_t bk; // bounce index b | sample index k << 16 (k: frame inside a batched launch, 0 otherwise)
+  PT_DEV uint32_t x() const { return xy & 0xffffu; }
+  PT_DEV uint32_t y() const { return xy >> 16; }
+  PT_DEV uint32_t b() const { return bk & 0xffffu; }
+  PT_DEV uint32_t k() const { return bk >> 16; }
 };
 
 // kernel() prologue: seed, generateRay, camera_dof (raytrace.cu:227-240)
@@ -473,10 +476,8 @@ PT_DEV void path_begin(const KParams& p, uint32_t x, uint32_t y, Path& st, uint3
   st.throughput = mk3(1.0f);
   st.acc = mk3(0.0f);
   st.specular_col = 0.0f;
-  st.b = 0;
-  st.x = x;
-  st.y = y;
-  st.k = k;
+  st.xy = x | (y << 16);
+  st.bk = k << 16;
 }
 
 // One iteration of radiance()'s loop (raytrace.cu:67-207) is split around the nearest-hit search
@@ -512,9 +513,10 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
     for (;;) {
       st.acc = st.acc + env * st.throughput;
       const float pmax = __builtin_fmaxf(st.throughput.x, __builtin_fmaxf(st.throughput.y, st.throughput.z));
-      if (r1 > pmax && st.b > 1) return true;
+      if (r1 > pmax && st.b() > 1u) return true;
       st.throughput = st.throughput * (1.0f / pmax);
-      if (++st.b >= max_bounces) return true;
+      ++st.bk;
+      if ((int)st.b() >= max_bounces) return true;
       r1 = xorwow_uniform(st.rng);
       if (STATS) cnt.rays++; // the reference issues this (futile) intersect() call; count it as a ray
     }
@@ -575,9 +577,10 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
     }
   }
   const float pmax = __builtin_fmaxf(st.throughput.x, __builtin_fmaxf(st.throughput.y, st.throughput.z));
-  if (r1 > pmax && st.b > 1) return true;
+  if (r1 > pmax && st.b() > 1u) return true;
   st.throughput = st.throughput * (1.0f / pmax);
-  return ++st.b >= max_bounces;
+  ++st.bk;
+  return (int)st.b() >= max_bounces;
 }
 
 // ---------------------------------------------------------------- post process
@@ -634,7 +637,7 @@ PT_DEV bool path_step(const KParams& p, const float4* s_nodes, const float4* s_t
 PT_DEV void path_finish(const KParams& p, const Path& st)
 {
   f3 rad = mk3(clamp01(st.acc.x), clamp01(st.acc.y), clamp01(st.acc.z));
-  const uint32_t x = st.x, y = st.y;
+  const uint32_t x = st.x(), y = st.y();
   // row-flipped accumulator index (raytrace.cu:252)
   const size_t i = (size_t)(p.height - y - 1u - p.tfb_row0) * p.width + x;
   float* tp = p.tfb + i * 3;
@@ -657,7 +660,7 @@ PT_DEV void path_finish(const KParams& p, const Path& st)
 PT_DEV void path_finish_sample(const KParams& p, const Path& st)
 {
   const uint32_t rows = p.row_end - p.row_begin;
-  float* sp = p.samples_out + (((size_t)st.k * rows + (st.y - p.row_begin)) * p.width + st.x) * 3;
+  float* sp = p.samples_out + (((size_t)st.k() * rows + (st.y() - p.row_begin)) * p.width + st.x()) * 3;
   sp[0] = clamp01(st.acc.x); sp[1] = clamp01(st.acc.y); sp[2] = clamp01(st.acc.z);
 }
 
@@ -748,7 +751,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
   Path st;
   st.o = st.d = st.throughput = st.acc = mk3(0.f);
   st.rng.v0 = st.rng.v1 = st.rng.v2 = st.rng.v3 = st.rng.v4 = st.rng.d = 0;
-  st.specular_col = 0.f; st.b = 0; st.x = st.y = 0;
+  st.specular_col = 0.f; st.xy = 0; st.bk = 0;
   bool idle = true;        // this lane has no path in flight
   bool has_output = false; // ... but holds a finished, not yet written sample
   // wave-uniform tile queue.  A ticket is `tiles_per_ticket` consecutive 8x8 tiles; a wave's
@@ -867,7 +870,7 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
     Path st;
     bool live = active;
     if (active) path_begin(p, x, y, st);
-    else { st.o = st.d = st.throughput = st.acc = mk3(0.f); st.b = 0; st.x = st.y = 0; st.specular_col = 0.f;
+    else { st.o = st.d = st.throughput = st.acc = mk3(0.f); st.xy = 0; st.bk = 0; st.specular_col = 0.f;
            st.rng.v0 = st.rng.v1 = st.rng.v2 = st.rng.v3 = st.rng.v4 = st.rng.d = 0; }
 
     // bounce 0: primary rays are coherent and all lanes are live — trace in place
