@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "indoor.scene"))
     ap.add_argument("--tessellate", type=int, default=1, help="split every face into n*n (24 -> ~257k tris, configs[3])")
     ap.add_argument("--aperture", type=float, default=None, help="override the camera aperture (configs[4]: 0.113)")
-    ap.add_argument("--kernel", choices=["persistent", "bvh", "blockwise", "brute"], default="persistent")
+    ap.add_argument("--kernel", choices=["persistent", "split", "bvh", "blockwise", "brute"], default="persistent")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate HIP streams, each with its own context and "
                          "buffers (double buffering, as the reference double-buffers its GL renderbuffers: "
@@ -149,7 +149,7 @@ def main():
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
     kernel = {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
-              "blockwise": P.KERNEL_BVH_BLOCKWISE}[args.kernel]
+              "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT}[args.kernel]
     hs = P.HostScene.load(args.scene)
     if args.tessellate > 1:
         hs = P.tessellate(hs, args.tessellate)
@@ -159,7 +159,7 @@ def main():
     n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world > 1 else 1)
     dev = torch.device("cuda", local_rank)
     y0, y1 = P.row_bands(H, world)[rank]
-    batched = (not args.sequential) and args.kernel == "persistent" and spp > 1
+    batched = (not args.sequential) and args.kernel in ("persistent", "split") and spp > 1
 
     class Slot:
         """One frame in flight: its own context (ticket counters, sample scratch), buffers and stream."""
@@ -271,7 +271,7 @@ def main():
                        "parallelism": f"rows/{world}" + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": {"persistent": "pt_megakernel_persistent", "blockwise": "pt_megakernel_blockwise"}.get(args.kernel, "pt_megakernel"), "kernel_ms_per_launch": round(kern_ms, 4),
+                         "kernel": {"persistent": "pt_megakernel_persistent", "blockwise": "pt_megakernel_blockwise", "split": "pt_megakernel_split"}.get(args.kernel, "pt_megakernel"), "kernel_ms_per_launch": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes_launch),
                          "samples_per_launch": int(stats["samples"] / spp * frames_per_launch),
                          "algorithmic_bytes_per_sample": round(alg_bytes_frame / max(stats["samples"], 1), 1),

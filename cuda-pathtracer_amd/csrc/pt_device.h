@@ -215,6 +215,7 @@ struct KParams {
   uint32_t tfb_row0;  // buffers hold frame rows starting here (0 for full-frame buffers)
   uint32_t surf_row0;
   unsigned long long* stats; // 8 counters or nullptr
+  unsigned long long* error_flag; // incremented when a bounded spin of the split kernel times out
   // persistent variant: 8x8 tiles over the row band, handed out by a ticket counter
   uint32_t* tile_counter;
   uint32_t tiles_x, n_tiles, tiles_per_ticket;

@@ -28,6 +28,18 @@ namespace ptamd {
 #ifndef PT_TILE_WAVES_PER_EU
 #define PT_TILE_WAVES_PER_EU 6
 #endif
+#ifndef PT_SP_THREADS
+#define PT_SP_THREADS 768
+#endif
+#ifndef PT_SP_SHADERS
+#define PT_SP_SHADERS 7
+#endif
+#ifndef PT_SP_WAVES_PER_EU
+#define PT_SP_WAVES_PER_EU 6
+#endif
+#ifndef PT_SP_FETCH_MIN
+#define PT_SP_FETCH_MIN 16u
+#endif
 #ifndef PT_BW_THREADS
 #define PT_BW_THREADS 512
 #endif
@@ -42,6 +54,9 @@ namespace ptamd {
 #endif
 #ifndef PT_PERSISTENT_THREADS
 #define PT_PERSISTENT_THREADS 512
+#endif
+#ifndef PT_LEAF_MIN
+#define PT_LEAF_MIN 64u /* lanes parked at a leaf that end a box phase early (64 = only when all are parked) */
 #endif
 #ifndef PT_ASM_WALK
 #define PT_ASM_WALK 1
@@ -133,6 +148,7 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
   leaf_first = 0;
   leaf_count = 0;
   uint32_t node = w.node;
+  const uint32_t lanes_in = (uint32_t)__popcll(__ballot(node != PT_END)); // walkers entering the box phase
   while (node != PT_END) {
     const float4 q0 = nodes[node * 4 + 0];
     const float4 q1 = nodes[node * 4 + 1];
@@ -161,6 +177,9 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
       leaf_count = count;
       break;
     }
+    // leave the box phase early once PT_LEAF_MIN lanes of the wave are parked at a leaf: they
+    // would otherwise idle until the slowest walker finds its own (the walkers keep their place)
+    if (PT_LEAF_MIN < 64 && (uint32_t)__popcll(__ballot(1)) + PT_LEAF_MIN <= lanes_in) break;
   }
   w.node = node;
 }
@@ -176,9 +195,12 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
 {
   uint32_t node = w.node, first, count;
   const uint32_t lnk = lds_nodes + w.link_off * 4u; // byte address of this octant's link in node 0
-  unsigned long long save, m_a, m_b, m_int, m_leaf;
+  unsigned long long save, m_a, m_b, m_int, m_leaf, parked;
+  uint32_t npark;
+  const uint32_t leaf_min = PT_LEAF_MIN; // the loop also ends when this many lanes hold a leaf
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b64 %[parked], 0\n\t"
       "v_mov_b32 %[first], 0\n\t"
       "v_mov_b32 %[count], 0\n\t"
       "v_cmp_ne_u32 vcc, -1, %[node]\n\t"
@@ -228,14 +250,19 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
       "v_cndmask_b32 %[count], %[count], v68, %[mleaf]\n\t"
       "v_cmp_ne_u32 vcc, -1, %[node]\n\t"
       "s_andn2_b64 vcc, vcc, %[mleaf]\n\t"             // keep walking: not at a hit leaf and not off the tree
+      "s_or_b64 %[parked], %[parked], %[mleaf]\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
-      "s_cbranch_execnz 1b\n\t"
+      "s_cbranch_execz 2f\n\t"
+      "s_bcnt1_i32_b64 %[npark], %[parked]\n\t"        // enough lanes parked at a leaf: end the box phase early
+      "s_cmp_lt_u32 %[npark], %[leafmin]\n\t"
+      "s_cbranch_scc1 1b\n\t"
       "2:\n\t"
       "s_mov_b64 exec, %[save]\n\t"
       : [node] "+v"(node), [first] "=&v"(first), [count] "=&v"(count), [save] "=&s"(save), [ma] "=&s"(m_a),
-        [mb] "=&s"(m_b), [mint] "=&s"(m_int), [mleaf] "=&s"(m_leaf)
+        [mb] "=&s"(m_b), [mint] "=&s"(m_int), [mleaf] "=&s"(m_leaf), [parked] "=&s"(parked), [npark] "=&s"(npark)
       : [lnk] "v"(lnk), [base] "v"(lds_nodes), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
-        [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t), [oct] "v"(w.oct)
+        [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t), [oct] "v"(w.oct),
+        [leafmin] "s"(leaf_min)
       : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "vcc", "scc", "memory");
   leaf_first = first;
   leaf_count = count;
@@ -272,8 +299,9 @@ PT_DEV void traverse_bvh(const float4* nodes, const float4* tris, uint32_t n_nod
     uint32_t leaf_first, leaf_count;
     if (NODES_IN_LDS && !STATS && PT_ASM_WALK) walk_to_leaf_lds(lds_nodes, w, leaf_first, leaf_count);
     else walk_to_leaf<STATS>(nodes, w, leaf_first, leaf_count, n_nodes_visited, wave_node_iters);
-    if (leaf_count == 0) break;
-    walk_leaf<STATS>(tris, w, leaf_first, leaf_count, n_tris, wave_tri_iters);
+    // a box phase can end early (PT_LEAF_MIN) with this lane still walking: no leaf and not at the end
+    if (leaf_count != 0u) walk_leaf<STATS>(tris, w, leaf_first, leaf_count, n_tris, wave_tri_iters);
+    else if (w.node == PT_END) break;
   }
   best = w.best;
 }
@@ -300,7 +328,7 @@ PT_DEV int texture_idx(const TexDesc& tex, float uvx, float uvy)
   return (y * tex.w + x) * tex.nb_chan;
 }
 
-struct Counters { uint32_t rays, nodes, tris, mesh_hits, nmap_hits, wave_node_iters, wave_tri_iters; };
+struct Counters { uint32_t rays, nodes, tris, mesh_hits, nmap_hits, wave_node_iters, wave_tri_iters, fetch_events, fetch_rays; };
 
 // Result of the nearest-hit search of one intersect() call, before any shading data is touched:
 // 16 bytes, which is what travels through LDS when rays are compacted across a workgroup.
@@ -669,9 +697,9 @@ PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t sampl
 {
   if (!STATS) return;
   const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long v[8] = { cnt.rays, cnt.nodes, cnt.tris, cnt.mesh_hits, cnt.nmap_hits, samples,
-                              cnt.wave_node_iters, cnt.wave_tri_iters };
-  for (int k = 0; k < 8; ++k) {
+  unsigned long long v[10] = { cnt.rays, cnt.nodes, cnt.tris, cnt.mesh_hits, cnt.nmap_hits, samples,
+                               cnt.wave_node_iters, cnt.wave_tri_iters, cnt.fetch_events, cnt.fetch_rays };
+  for (int k = 0; k < 10; ++k) {
     unsigned long long s = v[k];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && s) atomicAdd(&p.stats[k], s);
@@ -716,7 +744,7 @@ __global__ void __launch_bounds__(BLOCK, PT_TILE_WAVES_PER_EU) pt_megakernel(con
   const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
   const uint32_t y = p.row_begin + blockIdx.y * (BLOCK / 16u) + (wave >> 1) * 8u + (lane >> 3);
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
   const bool active = x < p.width && y < p.row_end;
   if (active) {
     Path st;
@@ -745,7 +773,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
 
   const uint32_t lane = threadIdx.x & 63u;
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
   uint32_t samples = 0;
 
   Path st;
@@ -856,7 +884,7 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
   uint32_t samples = 0;
   uint32_t ticket = blockIdx.x; // first super-tile is static, later ones come from the counter
 
@@ -948,7 +976,7 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
             walk_to_leaf<STATS>(s_nodes, w, leaf_first, leaf_count, cnt.nodes, cnt.wave_node_iters);
             if (leaf_count != 0u) {
               walk_leaf<STATS>(s_tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters);
-            } else {
+            } else if (w.node == PT_END) {
               // walk over: publish the face-search result in the ray's own slot
               pool[my_ray * 2u + 0u] = make_float4(w.best.t, w.best.u, w.best.v, u_as_f(w.best.idx));
               have = false;
@@ -975,6 +1003,185 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
     if (tid == 0) *s_ticket = atomicAdd(p.tile_counter, 1u);
     __syncthreads();
     ticket = *s_ticket;
+  }
+  flush_counters<STATS>(p, cnt, samples);
+}
+
+// ---------------------------------------------------------------- the megakernel, split form
+
+// Shader waves and traverser waves (producer/consumer inside one workgroup, no barriers).
+//
+// The box-test loop runs at 33 % lane utilisation when every lane owns one path: a wave waits for
+// its longest walk, and paths that ended leave holes.  Here the walk is taken away from the path's
+// lane.  A workgroup has PT_SP_SHADERS "shader" waves, which own the path state (64 paths each,
+// exactly the persistent kernel's per-lane state machine) and never walk the tree, and
+// PT_SP_TRAVERSERS "traverser" waves, which own no paths: they pull rays from whatever the shader
+// waves have published in LDS and keep their 64 lanes busy by restarting a lane on the next ray
+// as soon as PT_SP_FETCH_MIN lanes have finished (ballot + popcount, rank = mbcnt) — rays of
+// different pixels, waves and bounce depths share one walk loop, which is fine because nothing
+// but the (t, index) minimum of each individual ray matters.
+//
+// Protocol per shader wave w (all words in LDS, workgroup-scope atomics, bounded spins):
+//   publish   write n rays to rays[w][0..n), done[w] = 0, then ONE store  word[w] = n << 16
+//   claim     a traverser does  old = atomicAdd(word[w], k);  it owns rays
+//             [old & 0xffff, min((old & 0xffff) + k, old >> 16))  — only the value the add
+//             RETURNS is trusted, never an earlier read
+//   result    the traverser lane overwrites its ray slot with {t, u, v, idx}, then atomicAdd(done[w], 1)
+//   retire    the shader wave spins until done[w] == n, stores word[w] = 0, reads its results, shades
+// LDS operations of one wave execute in order, so "write rays, then publish" and "write result,
+// then count it" need no more than a compiler-level fence.
+template <bool LDS_RESIDENT, bool STATS>
+__global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakernel_split(const KParams p)
+{
+  constexpr uint32_t NW = PT_SP_THREADS / 64u, NS = PT_SP_SHADERS, NT = NW - NS;
+  static_assert(NS >= 1 && NT >= 1, "need at least one shader wave and one traverser wave");
+  extern __shared__ float4 s_mem[];
+  const float4* s_nodes;
+  const float4* s_tris;
+  stage_scene<2, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris); // zeroes nothing: control words are set below
+  float4* rays = s_mem + (LDS_RESIDENT ? (p.n_nodes * 4u + p.n_bvh_tris * 3u) : 0u); // [NS][64][2]
+  uint32_t* word = reinterpret_cast<uint32_t*>(rays + NS * 64u * 2u);               // [NS] n << 16 | claimed
+  uint32_t* done = word + NS;                                                          // [NS]
+  uint32_t* fin = done + NS;                                                           // shader waves finished
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid < NS) { word[tid] = 0u; done[tid] = 0u; }
+  if (tid == 0) *fin = 0u;
+  __syncthreads(); // the only barrier: control words initialised (stage_scene's barrier came before the stores)
+
+  Counters cnt;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
+  uint32_t samples = 0;
+  const uint32_t spin_limit = 1u << 26; // bounded spins: a protocol bug must not hang the GPU
+
+  if (wave < NS) {
+    // ------------------------------------------------------------ shader wave
+    float4* my_rays = rays + wave * 128u;
+    const uint32_t total = p.n_tiles * p.sample_count;
+    uint32_t ticket = blockIdx.x * NS + wave; // first tile is static, later ones come from the counter
+    bool failed = false;
+    while (ticket < total && !failed) {
+      const uint32_t k = ticket / p.n_tiles, tl = ticket - k * p.n_tiles;
+      const uint32_t x = (tl % p.tiles_x) * 8u + (lane & 7u);
+      const uint32_t y = p.row_begin + (tl / p.tiles_x) * 8u + (lane >> 3);
+      const bool active = x < p.width && y < p.row_end;
+      Path st;
+      if (active) path_begin(p, x, y, st, k);
+      else { st.o = st.d = st.throughput = st.acc = mk3(0.f); st.xy = 0; st.bk = 0; st.specular_col = 0.f;
+             st.rng.v0 = st.rng.v1 = st.rng.v2 = st.rng.v3 = st.rng.v4 = st.rng.d = 0; }
+      bool live = active;
+      for (;;) {
+        const unsigned long long m = __ballot(live);
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (n == 0) break;
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        float r1 = 0.f;
+        if (live) {
+          r1 = path_pre(p, st);
+          my_rays[slot * 2u + 0u] = make_float4(st.d.x, st.d.y, st.d.z, st.o.x);
+          my_rays[slot * 2u + 1u] = make_float4(st.o.y, st.o.z, 0.f, 0.f);
+          if (STATS) cnt.rays++;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) {
+          __hip_atomic_store(&done[wave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&word[wave], n << 16, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // wait for the traversers
+        uint32_t spins = 0, d = 0;
+        do {
+          d = __hip_atomic_load(&done[wave], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+          if (d != n) __builtin_amdgcn_s_sleep(2);
+        } while (d != n && ++spins < spin_limit);
+        if (d != n) { failed = true; break; }
+        if (lane == 0) __hip_atomic_store(&word[wave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (live) {
+          const float4 h = my_rays[slot * 2u + 0u];
+          Nearest nr;
+          nr.t = h.x; nr.u = h.y; nr.v = h.z; nr.idx = f_as_u(h.w);
+          nr = nearest_lights(p, st.o, st.d, nr);
+          live = !path_post<STATS>(p, st, r1, nr, cnt);
+        }
+      }
+      if (failed) break;
+      if (active) {
+        if (p.sample_count > 1u) path_finish_sample(p, st);
+        else path_finish(p, st);
+        if (STATS) samples++;
+      }
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(p.tile_counter, 1u);
+      ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    }
+    if (failed && lane == 0) atomicAdd(p.error_flag, 1ull); // protocol time-out (ptamd_device_error_count)
+    if (lane == 0) __hip_atomic_fetch_add(fin, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    // ------------------------------------------------------------ traverser wave
+    Walk w;
+    w.node = PT_END; w.oct = 0; w.link_off = 8u;
+    w.o = w.d = w.inv = w.noi = mk3(0.f);
+    w.best.t = PT_MAX_DIST; w.best.u = w.best.v = 0.f; w.best.idx = PT_END;
+    const uint32_t lds_nodes = (uint32_t)(uintptr_t)s_nodes;
+    bool have = false;
+    uint32_t my_slot = 0; // batch << 8 | ray index
+    uint32_t scan = (wave - NS) % NS, idle_spins = 0;
+    for (;;) {
+      const unsigned long long idle_mask = __ballot(!have);
+      const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+      if (n_idle >= PT_SP_FETCH_MIN || idle_mask == ~0ull) {
+        // look for a batch with unclaimed rays, starting where the last one was found
+        uint32_t got = 0, base = 0, b = scan;
+        for (uint32_t tries = 0; tries < NS && got == 0; ++tries) {
+          uint32_t wd = __hip_atomic_load(&word[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          wd = (uint32_t)__builtin_amdgcn_readfirstlane((int)wd);
+          if ((wd & 0xffffu) < (wd >> 16)) {
+            uint32_t old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(&word[b], n_idle, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+            const uint32_t on = old >> 16, oc = old & 0xffffu;
+            if (oc < on) { base = oc; got = on - oc < n_idle ? on - oc : n_idle; }
+          }
+          if (got == 0) b = b + 1u == NS ? 0u : b + 1u;
+        }
+        scan = b;
+        if (got) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+          if (!have && rank < got) {
+            const uint32_t r = base + rank;
+            const float4 ra = rays[(b * 64u + r) * 2u + 0u], rb = rays[(b * 64u + r) * 2u + 1u];
+            walk_init(w, mk3(ra.w, rb.x, rb.y), mk3(ra.x, ra.y, ra.z), p.n_nodes);
+            have = true;
+            my_slot = (b << 8) | r;
+          }
+          idle_spins = 0;
+          if (STATS && lane == 0) { cnt.fetch_events++; cnt.fetch_rays += got; }
+        } else if (idle_mask == ~0ull) {
+          // nothing to do: leave when every shader wave is finished, else nap and look again
+          uint32_t f = __hip_atomic_load(fin, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          f = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+          if (f == NS || ++idle_spins >= spin_limit) break;
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+      }
+      if (have) {
+        uint32_t leaf_first, leaf_count;
+        if (LDS_RESIDENT && !STATS && PT_ASM_WALK) walk_to_leaf_lds(lds_nodes, w, leaf_first, leaf_count);
+        else walk_to_leaf<STATS>(s_nodes, w, leaf_first, leaf_count, cnt.nodes, cnt.wave_node_iters);
+        if (leaf_count != 0u) {
+          walk_leaf<STATS>(s_tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters);
+        } else if (w.node == PT_END) {
+          const uint32_t b = my_slot >> 8, r = my_slot & 0xffu;
+          rays[(b * 64u + r) * 2u + 0u] = make_float4(w.best.t, w.best.u, w.best.v, u_as_f(w.best.idx));
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __hip_atomic_fetch_add(&done[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          have = false;
+        }
+      }
+    }
   }
   flush_counters<STATS>(p, cnt, samples);
 }
@@ -1017,7 +1224,7 @@ __global__ void __launch_bounds__(256) pt_trace_rays_kernel(const KParams p, con
   const f3 d = mk3(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
   const f3 o = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
   const Nearest nr = trace_nearest<KIND, false>(p, p.nodes, KIND == 1 ? p.tris_brute : p.tris_bvh, o, d, cnt);
   const int kind = nr.idx == PT_END ? 0 : ((nr.idx & PT_LIGHT) ? 2 : 1);
   const int index = kind == 0 ? -1 : (int)(nr.idx & ~PT_LIGHT);
@@ -1095,6 +1302,49 @@ hipError_t launch_megakernel_persistent(const KParams& p, bool lds_resident, siz
   KParams pc = p;
   void* args[] = { &pc };
   return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_PERSISTENT_THREADS), args, lds_bytes, stream);
+}
+
+static const void* split_select(bool lds_resident, bool stats)
+{
+  if (lds_resident)
+    return stats ? reinterpret_cast<const void*>(pt_megakernel_split<true, true>)
+                 : reinterpret_cast<const void*>(pt_megakernel_split<true, false>);
+  return stats ? reinterpret_cast<const void*>(pt_megakernel_split<false, true>)
+               : reinterpret_cast<const void*>(pt_megakernel_split<false, false>);
+}
+
+// LDS of the split variant = staged scene (when resident) + ray batches of the shader waves + control words
+size_t split_lds_bytes(bool lds_resident, size_t scene_lds_bytes)
+{
+  return (lds_resident ? scene_lds_bytes : 0) + (size_t)PT_SP_SHADERS * 64u * 32u + (2u * PT_SP_SHADERS + 4u) * 4u;
+}
+
+uint32_t split_shader_waves() { return PT_SP_SHADERS; }
+
+hipError_t split_blocks_per_cu(bool lds_resident, size_t scene_lds_bytes, int* out)
+{
+  const size_t lds = split_lds_bytes(lds_resident, scene_lds_bytes);
+  const void* fn = split_select(lds_resident, false);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, PT_SP_THREADS, lds);
+}
+
+hipError_t launch_megakernel_split(const KParams& p, bool lds_resident, size_t scene_lds_bytes, bool stats,
+                                   uint32_t n_blocks, hipStream_t stream)
+{
+  if (p.n_tiles == 0 || n_blocks == 0) return hipSuccess;
+  const size_t lds = split_lds_bytes(lds_resident, scene_lds_bytes);
+  const void* fn = split_select(lds_resident, stats);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  KParams pc = p;
+  void* args[] = { &pc };
+  return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_SP_THREADS), args, lds, stream);
 }
 
 static const void* blockwise_select(bool lds_resident, bool stats)

@@ -17,6 +17,10 @@ hipError_t launch_megakernel_persistent(const KParams& p, bool lds_resident, siz
 hipError_t blockwise_blocks_per_cu(bool lds_resident, size_t scene_lds_bytes, int* out);
 hipError_t launch_megakernel_blockwise(const KParams& p, bool lds_resident, size_t scene_lds_bytes, bool stats,
                                        uint32_t n_blocks, hipStream_t stream);
+uint32_t split_shader_waves();
+hipError_t split_blocks_per_cu(bool lds_resident, size_t scene_lds_bytes, int* out);
+hipError_t launch_megakernel_split(const KParams& p, bool lds_resident, size_t scene_lds_bytes, bool stats,
+                                   uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_resolve(const KParams& p, hipStream_t stream);
 hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,
                              hipStream_t stream);

@@ -60,6 +60,7 @@ struct ptamd_context {
   int n_cus = 0;
   int blocks_per_cu[2] = { -1, -1 }; // [lds_resident]
   int bw_blocks_per_cu[2] = { -1, -1 };
+  int sp_blocks_per_cu[2] = { -1, -1 };
   float* d_samples = nullptr; // parked samples of batched launches (grown on demand)
   size_t samples_bytes = 0;
   uint32_t default_kernel = PTAMD_KERNEL_BVH_PERSISTENT; // what PTAMD_KERNEL_AUTO means
@@ -140,7 +141,7 @@ int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
   if (l->bounces == 0 || l->bounces > 1024) { set_error("ptamd_raytrace: bounces out of range (1..1024)"); return PTAMD_ERR_ARG; }
   if (l->frame_count > 4096) { set_error("ptamd_raytrace: frame_count out of range (<= 4096)"); return PTAMD_ERR_ARG; }
   if (l->frame_count > 1 && l->moved) { set_error("ptamd_raytrace: batched frames must be static (moved = 0)"); return PTAMD_ERR_ARG; }
-  if (l->kernel > PTAMD_KERNEL_BVH_BLOCKWISE) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
+  if (l->kernel > PTAMD_KERNEL_BVH_SPLIT) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
   return PTAMD_OK;
 }
 
@@ -185,6 +186,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     p.surf_row0 = l->row_begin;
   }
   p.stats = stats ? ctx->d_stats : nullptr;
+  p.error_flag = ctx->d_stats + 15;
 
   int kind = l->kernel == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2;
   const size_t lds = kind == 1 ? s.info.lds_bytes_brute : s.info.lds_bytes_bvh;
@@ -192,8 +194,8 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   hipStream_t stream = static_cast<hipStream_t>(l->stream);
   hipError_t e;
   const uint32_t which = l->kernel == PTAMD_KERNEL_AUTO ? ctx->default_kernel : l->kernel;
-  if (l->frame_count > 1 && which != PTAMD_KERNEL_BVH_PERSISTENT) {
-    set_error("ptamd_raytrace: frame_count > 1 needs the persistent kernel (PTAMD_KERNEL_AUTO or _BVH_PERSISTENT)");
+  if (l->frame_count > 1 && which != PTAMD_KERNEL_BVH_PERSISTENT && which != PTAMD_KERNEL_BVH_SPLIT) {
+    set_error("ptamd_raytrace: frame_count > 1 needs a persistent kernel (PTAMD_KERNEL_AUTO, _BVH_PERSISTENT or _BVH_SPLIT)");
     return PTAMD_ERR_ARG;
   }
   if (which == PTAMD_KERNEL_BVH_BLOCKWISE) {
@@ -213,19 +215,21 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     p.tile_counter = ctx->d_tickets + (ctx->ticket_next++ % kTicketRing);
     PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)n_blocks, 1, stream));
     e = launch_megakernel_blockwise(p, resident, lds, stats, n_blocks, stream);
-  } else if (which == PTAMD_KERNEL_BVH_PERSISTENT) {
+  } else if (which == PTAMD_KERNEL_BVH_PERSISTENT || which == PTAMD_KERNEL_BVH_SPLIT) {
+    const bool split = which == PTAMD_KERNEL_BVH_SPLIT;
     const uint32_t count = l->frame_count > 1 ? l->frame_count : 1u;
 
     const uint32_t rows = l->row_end - l->row_begin;
     p.tiles_x = (l->width + 7u) / 8u;
     p.n_tiles = p.tiles_x * ((rows + 7u) / 8u);
     if (p.n_tiles == 0) return PTAMD_OK;
-    int& bpc = ctx->blocks_per_cu[resident ? 1 : 0];
+    int& bpc = split ? ctx->sp_blocks_per_cu[resident ? 1 : 0] : ctx->blocks_per_cu[resident ? 1 : 0];
     if (bpc < 0) {
-      e = persistent_blocks_per_cu(resident, lds, &bpc);
+      e = split ? split_blocks_per_cu(resident, lds, &bpc) : persistent_blocks_per_cu(resident, lds, &bpc);
       if (e != hipSuccess || bpc < 1) { bpc = -1; return hip_fail("occupancy query of the persistent kernel", e); }
     }
-    const uint32_t waves_per_block = kPersistentThreads / 64u;
+    // waves that take tile tickets: every wave of a persistent block, the shader waves of a split block
+    const uint32_t waves_per_block = split ? split_shader_waves() : kPersistentThreads / 64u;
     uint32_t n_blocks = (uint32_t)ctx->n_cus * (uint32_t)bpc;
     p.sample_count = count;
     p.frame_nb0 = l->frame_nb;
@@ -250,7 +254,8 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     // tickets 0..n_waves-1 are taken statically by the waves; the shared counter hands out the rest
     p.tile_counter = ctx->d_tickets + (ctx->ticket_next++ % kTicketRing);
     PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)(n_blocks * waves_per_block), 1, stream));
-    e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
+    if (split) { p.tiles_per_ticket = 1; e = launch_megakernel_split(p, resident, lds, stats, n_blocks, stream); }
+    else e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
     if (e == hipSuccess && count > 1) e = launch_resolve(p, stream);
   } else {
     e = launch_megakernel(p, kind, resident, lds, stats, stream);
@@ -295,7 +300,8 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   std::unique_ptr<ptamd_context> ctx(new (std::nothrow) ptamd_context());
   if (!ctx) { set_error("ptamd_create: out of memory"); return PTAMD_ERR_ARG; }
   ctx->device = device_ordinal;
-  PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), 8 * sizeof(unsigned long long)));
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), 16 * sizeof(unsigned long long)));
+  PT_HIP(hipMemset(ctx->d_stats, 0, 16 * sizeof(unsigned long long)));
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), kTicketRing * sizeof(uint32_t)));
   hipDeviceProp_t prop;
   PT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
@@ -306,7 +312,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   }
   if (const char* e = std::getenv("PTAMD_DEFAULT_KERNEL")) { // tuning knob: 1..4
     int v = std::atoi(e);
-    if (v >= 1 && v <= 4) ctx->default_kernel = (uint32_t)v;
+    if (v >= 1 && v <= 5) ctx->default_kernel = (uint32_t)v;
   }
   if (const char* e = std::getenv("PTAMD_TILES_PER_TICKET")) {
     int v = std::atoi(e);
@@ -468,15 +474,27 @@ int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_t
   if (!ctx || !out) { set_error("ptamd_raytrace_stats: null argument"); return PTAMD_ERR_ARG; }
   PT_HIP(hipSetDevice(ctx->device));
   hipStream_t st = launch ? static_cast<hipStream_t>(launch->stream) : nullptr;
-  PT_HIP(hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), st));
+  PT_HIP(hipMemsetAsync(ctx->d_stats, 0, 10 * sizeof(unsigned long long), st));
   int rc = do_launch(ctx, launch, true);
   if (rc != PTAMD_OK) return rc;
   PT_HIP(hipStreamSynchronize(st));
-  unsigned long long h[8];
+  unsigned long long h[10];
   PT_HIP(hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
   out->rays = h[0]; out->nodes_visited = h[1]; out->tris_tested = h[2];
   out->mesh_hits = h[3]; out->nmap_hits = h[4]; out->samples = h[5];
   out->wave_node_iters = h[6]; out->wave_tri_iters = h[7];
+  out->fetch_events = h[8]; out->fetch_rays = h[9];
+  return PTAMD_OK;
+}
+
+int ptamd_device_error_count(ptamd_context* ctx, uint64_t* out)
+{
+  if (!ctx || !out) { set_error("ptamd_device_error_count: null argument"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  PT_HIP(hipDeviceSynchronize());
+  unsigned long long v = 0;
+  PT_HIP(hipMemcpy(&v, ctx->d_stats + 15, sizeof v, hipMemcpyDeviceToHost));
+  *out = v;
   return PTAMD_OK;
 }
 

@@ -22,7 +22,7 @@ class PtamdError(RuntimeError):
 
 
 PTAMD_OK, PTAMD_ERR_ARG, PTAMD_ERR_HIP, PTAMD_ERR_IO, PTAMD_ERR_LIMIT = 0, 1, 2, 3, 4
-KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, KERNEL_BVH_PERSISTENT, KERNEL_BVH_BLOCKWISE = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, KERNEL_BVH_PERSISTENT, KERNEL_BVH_BLOCKWISE, KERNEL_BVH_SPLIT = 0, 1, 2, 3, 4, 5
 
 
 class Float3(C.Structure):
@@ -76,7 +76,8 @@ class Launch(C.Structure):
 class TraceStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("mesh_hits", C.c_uint64), ("nmap_hits", C.c_uint64), ("samples", C.c_uint64),
-                ("wave_node_iters", C.c_uint64), ("wave_tri_iters", C.c_uint64)]
+                ("wave_node_iters", C.c_uint64), ("wave_tri_iters", C.c_uint64),
+                ("fetch_events", C.c_uint64), ("fetch_rays", C.c_uint64)]
 
 
 class SceneInfo(C.Structure):
@@ -118,6 +119,7 @@ SIGNATURES = {
     "ptamd_wang_hash": (C.c_uint32, [C.c_uint32]),
     "ptamd_raytrace_stats": (C.c_int, [C.c_void_p, C.POINTER(Launch), C.POINTER(TraceStats)]),
     "ptamd_scene_info_get": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(SceneInfo)]),
+    "ptamd_device_error_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ptamd_trace_rays": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
                                    C.POINTER(C.c_int32)]),
     "ptamd_host_bvh_trace": (C.c_int, [C.POINTER(Face), C.c_uint32, C.POINTER(C.c_float), C.c_uint32,

@@ -147,6 +147,12 @@ class Context:
                                            len(rays), out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
+    def device_error_count(self) -> int:
+        """Protocol time-outs of the split kernel since creation (0 unless there is a bug); synchronises."""
+        v = C.c_uint64()
+        N.check(self._lib.ptamd_device_error_count(self._h, C.byref(v)))
+        return v.value
+
     def synchronize(self, stream=None) -> None:
         N.check(self._lib.ptamd_stream_synchronize(self._h, _stream_handle(stream)))
 

@@ -182,7 +182,8 @@ typedef enum {
   PTAMD_KERNEL_BRUTE_FORCE = 1,   /* the reference algorithm: every face, LDS-staged, wave-uniform; 1 thread = 1 pixel */
   PTAMD_KERNEL_BVH = 2,           /* stackless ordered BVH walk, LDS-staged nodes + triangles; 1 thread = 1 pixel */
   PTAMD_KERNEL_BVH_PERSISTENT = 3, /* same walk in persistent waves with mid-path lane refill (ballot + mbcnt) */
-  PTAMD_KERNEL_BVH_BLOCKWISE = 4  /* persistent workgroups; live rays of each bounce compacted + octant-sorted through LDS */
+  PTAMD_KERNEL_BVH_BLOCKWISE = 4, /* persistent workgroups; live rays of each bounce compacted + octant-sorted through LDS */
+  PTAMD_KERNEL_BVH_SPLIT = 5      /* shader waves own the paths, traverser waves pull their rays from LDS and restart lanes */
 } ptamd_kernel_kind;
 
 /* Explicit form used by the bench, the tests and the multi-GPU row split. */
@@ -221,6 +222,8 @@ typedef struct {
   uint64_t samples;         /* pixels rendered */
   uint64_t wave_node_iters; /* wave-level executions of the box-test loop body (lane utilisation = nodes_visited / (64 * this)) */
   uint64_t wave_tri_iters;  /* wave-level executions of the triangle-test loop body */
+  uint64_t fetch_events;    /* split kernel: wave-level ray fetches by traverser waves */
+  uint64_t fetch_rays;      /* split kernel: rays handed out by those fetches */
 } ptamd_trace_stats;
 
 /* Renders like ptamd_raytrace_ex with an instrumented build of the selected kernel and
@@ -232,6 +235,11 @@ typedef struct {
   uint32_t node_bytes, tri_bytes, lds_bytes_bvh, lds_bytes_brute;
 } ptamd_scene_info;
 int ptamd_scene_info_get(ptamd_context* ctx, uint32_t scene_id, ptamd_scene_info* out);
+
+/* Synchronises the device and returns how many times a bounded spin of the split kernel's
+ * producer/consumer protocol timed out since the context was created (always 0 unless there is a bug;
+ * a non-zero count means frames rendered by PTAMD_KERNEL_BVH_SPLIT are incomplete). */
+int ptamd_device_error_count(ptamd_context* ctx, uint64_t* out);
 
 /* Nearest-hit query on explicit rays through the device traversal (tests: BVH vs brute
  * force equivalence).  rays: n * {dir.xyz, origin.xyz}; out: n * {kind, index, t bits, pad}. */

@@ -1,9 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
-run() { python bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" 2>>$OUT/bench.err | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); r=d['roofline']
-print('$LABEL', d['value'], 'Msamples/s', d['ms_per_frame'], 'ms/frame kernel', r['kernel_ms_per_launch'], 'ms', d['config']['frames_in_flight'], d['rgba_checksum_rank0_band'])"; }
 python -c "import __graft_entry__ as g; g.build()" || exit 1
-for f in 1 2 3; do for h in 135 270 1080; do LABEL="rows$h-inflight$f" PTAMD_BENCH_FORCE_GATHER=1 run --kernel persistent --height $h --frames-in-flight $f; done; done
-tail -3 $OUT/bench.err
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+for k in persistent split; do timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --kernel $k 2>>$OUT/bench.err | cut -c1-120; done

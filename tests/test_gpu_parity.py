@@ -39,12 +39,12 @@ def assert_same(acc, rgba, ref_acc, ref_rgba, what=""):
     np.testing.assert_array_equal(rgba, ref_rgba, err_msg=what)
 
 
-KERNELS = ["blockwise", "persistent", "bvh", "brute"]
+KERNELS = ["persistent", "split", "blockwise", "bvh", "brute"]
 
 
 def kid(P, name):
     return {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
-            "blockwise": P.KERNEL_BVH_BLOCKWISE}[name]
+            "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT}[name]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -155,7 +155,7 @@ def test_row_band_split_is_bit_identical(P, gpu_ctx, indoor):
     ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
     W, H, spp, B = 200, 121, 2, 4
     full_acc, full_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
-    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE):
+    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         pa, pr = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, k, ids=ids)
         assert_same(pa, pr, full_acc, full_rgba, f"kernel {k} vs tile kernel")
     for world in (2, 3, 8):
@@ -202,6 +202,12 @@ def test_batched_frames_equal_consecutive_launches(P, O, gpu_ctx, indoor):
     fr.render(spp=5, bounces=3, batched=True)
     torch.cuda.synchronize()
     assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref, "batched vs oracle")
+    # the split kernel batches frames the same way
+    sp = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), 80, 48)
+    sp.render(spp=5, bounces=3, batched=True, kernel=P.KERNEL_BVH_SPLIT)
+    torch.cuda.synchronize()
+    assert_same(sp.accum.cpu().numpy(), sp.surface.cpu().numpy(), *ref, "batched split kernel vs oracle")
+    assert gpu_ctx.device_error_count() == 0          # no producer/consumer spin ever timed out
     l = gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), 80, 48, frame_nb=1, frame_count=3, moved=True)
     with pytest.raises(P.PtamdError):
         gpu_ctx.raytrace_ex(l)
@@ -239,7 +245,7 @@ def test_large_scene_uses_global_memory_variant(P, O, gpu_ctx):
     info = gpu_ctx.scene_info(sid)
     assert info["lds_bytes_bvh"] > 64 * 1024
     ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 48, 32, spp=2, bounces=3)
-    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE):
+    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 3, k)
         assert_same(acc, rgba, *ref, f"global-memory BVH kernel {k}")
 
@@ -252,7 +258,7 @@ def test_full_size_properties_1080p_4spp_4bounces(P, O, gpu_ctx, indoor):
     W, H, spp, B = 1920, 1080, 4, 4
     bvh_acc, bvh_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_AUTO, ids=ids)
     # (0) persistent waves with lane refill == one-thread-per-pixel walk
-    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE):
+    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         t_acc, t_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, k, ids=ids)
         assert_same(bvh_acc, bvh_rgba, t_acc, t_rgba, f"1080p default kernel vs kernel {k}")
     # (1) the BVH walk returns the brute-force loop's result for every ray of every path
@@ -290,7 +296,7 @@ def test_config4_sponza_class_deep_bvh(P, O, gpu_ctx, indoor):
     info = gpu_ctx.scene_info(ids[0])
     assert info["lds_bytes_bvh"] > 20 * 1024 * 1024 and info["depth"] >= 18
     ref = O.render(O.OracleScene.from_host_scene(big, cube), O.camera_from_record(big.camera), 64, 36, spp=1, bounces=3)
-    for k in (P.KERNEL_AUTO, P.KERNEL_BVH, P.KERNEL_BVH_BLOCKWISE):
+    for k in (P.KERNEL_AUTO, P.KERNEL_BVH, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         acc, rgba = gpu_render(P, gpu_ctx, big, cube, 64, 36, 1, 3, k, ids=ids)
         assert_same(acc, rgba, *ref, f"sponza-class kernel {k}")
     a0, r0 = gpu_render(P, gpu_ctx, big, cube, 1920, 1080, 1, 4, P.KERNEL_AUTO, ids=ids)
@@ -324,7 +330,7 @@ def test_stats_are_consistent(P, O, gpu_ctx, indoor):
     l = gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), W, H, frame_nb=1, bounces=4, kernel=P.KERNEL_BVH)
     s_bvh = gpu_ctx.raytrace_stats(l)
     fr.reset()
-    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE):
+    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         fr.reset()
         l.kernel = k
         s_k = gpu_ctx.raytrace_stats(l)
