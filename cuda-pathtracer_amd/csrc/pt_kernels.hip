@@ -120,6 +120,9 @@ struct Walk {
   uint32_t oct;
   uint32_t node;     // next node to test, PT_END when the walk is over
   Best best;
+  // STATS builds only: where the idle lane-slots of the box loop come from
+  uint32_t alive;    // lanes of the wave that trace a ray in this call
+  uint32_t idle_unstarted, idle_finished, idle_parked;
 };
 
 PT_DEV void walk_init(Walk& w, f3 o, f3 d, uint32_t n_nodes)
@@ -137,6 +140,7 @@ PT_DEV void walk_init(Walk& w, f3 o, f3 d, uint32_t n_nodes)
   w.link_off = 8u + w.oct;
   w.node = n_nodes ? 0u : PT_END;
   w.best.t = PT_MAX_DIST; w.best.u = 0.f; w.best.v = 0.f; w.best.idx = PT_END;
+  w.alive = 64u; w.idle_unstarted = w.idle_finished = w.idle_parked = 0u;
 }
 
 // Box tests until this lane holds a leaf (leaf_count != 0) or its walk is over.
@@ -157,7 +161,13 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
       ++n_nodes_visited;
       // one lane per executing wave counts the wave-level iteration (lane utilisation = nodes / (64 * iters))
       const unsigned long long act = __ballot(1);
-      if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) ++wave_node_iters;
+      if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) {
+        ++wave_node_iters;
+        const uint32_t active = (uint32_t)__popcll(act);
+        w.idle_unstarted += 64u - w.alive;       // no ray in this call (dead path, edge of the frame)
+        w.idle_finished += w.alive - lanes_in;   // walk already over, waiting for the wave
+        w.idle_parked += lanes_in - active;      // left this box phase (leaf found or walk just ended)
+      }
     }
     const float t0x = __builtin_fmaf(q0.x, w.inv.x, w.noi.x), t1x = __builtin_fmaf(q1.x, w.inv.x, w.noi.x);
     const float t0y = __builtin_fmaf(q0.y, w.inv.y, w.noi.y), t1y = __builtin_fmaf(q1.y, w.inv.y, w.noi.y);
@@ -289,10 +299,11 @@ PT_DEV void walk_leaf(const float4* tris, Walk& w, uint32_t leaf_first, uint32_t
 template <bool STATS, bool NODES_IN_LDS = false>
 PT_DEV void traverse_bvh(const float4* nodes, const float4* tris, uint32_t n_nodes, f3 o, f3 d,
                          Best& best, uint32_t& n_nodes_visited, uint32_t& n_tris, uint32_t& wave_node_iters,
-                         uint32_t& wave_tri_iters)
+                         uint32_t& wave_tri_iters, uint32_t* idle3)
 {
   Walk w;
   walk_init(w, o, d, n_nodes);
+  if (STATS) w.alive = (uint32_t)__popcll(__ballot(1));
   // LDS byte address of the node table (low 32 bits of the flat address of an LDS object)
   const uint32_t lds_nodes = (uint32_t)(uintptr_t)nodes;
   for (;;) {
@@ -304,6 +315,7 @@ PT_DEV void traverse_bvh(const float4* nodes, const float4* tris, uint32_t n_nod
     else if (w.node == PT_END) break;
   }
   best = w.best;
+  if (STATS) { idle3[0] += w.idle_unstarted; idle3[1] += w.idle_finished; idle3[2] += w.idle_parked; }
 }
 
 // intersection.cuh:140-155 (see the oracle's note on the discarded conditional at :152)
@@ -328,7 +340,7 @@ PT_DEV int texture_idx(const TexDesc& tex, float uvx, float uvy)
   return (y * tex.w + x) * tex.nb_chan;
 }
 
-struct Counters { uint32_t rays, nodes, tris, mesh_hits, nmap_hits, wave_node_iters, wave_tri_iters, fetch_events, fetch_rays; };
+struct Counters { uint32_t rays, nodes, tris, mesh_hits, nmap_hits, wave_node_iters, wave_tri_iters, fetch_events, fetch_rays, idle3[3]; };
 
 // Result of the nearest-hit search of one intersect() call, before any shading data is touched:
 // 16 bytes, which is what travels through LDS when rays are compacted across a workgroup.
@@ -360,7 +372,7 @@ PT_DEV Nearest trace_nearest(const KParams& p, const float4* s_nodes, const floa
   best.t = PT_MAX_DIST; best.u = 0.f; best.v = 0.f; best.idx = PT_END;
   if (STATS) cnt.rays++;
   if (KIND == 1) traverse_brute<STATS>(s_tris, p.n_faces, o, d, best, cnt.tris);
-  else traverse_bvh<STATS, NODES_IN_LDS>(s_nodes, s_tris, p.n_nodes, o, d, best, cnt.nodes, cnt.tris, cnt.wave_node_iters, cnt.wave_tri_iters);
+  else traverse_bvh<STATS, NODES_IN_LDS>(s_nodes, s_tris, p.n_nodes, o, d, best, cnt.nodes, cnt.tris, cnt.wave_node_iters, cnt.wave_tri_iters, cnt.idle3);
   Nearest n;
   n.t = best.t; n.u = best.u; n.v = best.v; n.idx = best.idx;
   return nearest_lights(p, o, d, n);
@@ -697,9 +709,10 @@ PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t sampl
 {
   if (!STATS) return;
   const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long v[10] = { cnt.rays, cnt.nodes, cnt.tris, cnt.mesh_hits, cnt.nmap_hits, samples,
-                               cnt.wave_node_iters, cnt.wave_tri_iters, cnt.fetch_events, cnt.fetch_rays };
-  for (int k = 0; k < 10; ++k) {
+  unsigned long long v[13] = { cnt.rays, cnt.nodes, cnt.tris, cnt.mesh_hits, cnt.nmap_hits, samples,
+                               cnt.wave_node_iters, cnt.wave_tri_iters, cnt.fetch_events, cnt.fetch_rays,
+                               cnt.idle3[0], cnt.idle3[1], cnt.idle3[2] };
+  for (int k = 0; k < 13; ++k) {
     unsigned long long s = v[k];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && s) atomicAdd(&p.stats[k], s);
@@ -744,7 +757,7 @@ __global__ void __launch_bounds__(BLOCK, PT_TILE_WAVES_PER_EU) pt_megakernel(con
   const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
   const uint32_t y = p.row_begin + blockIdx.y * (BLOCK / 16u) + (wave >> 1) * 8u + (lane >> 3);
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
   const bool active = x < p.width && y < p.row_end;
   if (active) {
     Path st;
@@ -773,7 +786,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
 
   const uint32_t lane = threadIdx.x & 63u;
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
   uint32_t samples = 0;
 
   Path st;
@@ -884,7 +897,7 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
   uint32_t samples = 0;
   uint32_t ticket = blockIdx.x; // first super-tile is static, later ones come from the counter
 
@@ -1049,7 +1062,7 @@ __global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakern
   __syncthreads(); // the only barrier: control words initialised (stage_scene's barrier came before the stores)
 
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
   uint32_t samples = 0;
   const uint32_t spin_limit = 1u << 26; // bounded spins: a protocol bug must not hang the GPU
 
@@ -1224,7 +1237,7 @@ __global__ void __launch_bounds__(256) pt_trace_rays_kernel(const KParams p, con
   const f3 d = mk3(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
   const f3 o = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
   Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = 0;
+  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
   const Nearest nr = trace_nearest<KIND, false>(p, p.nodes, KIND == 1 ? p.tris_brute : p.tris_bvh, o, d, cnt);
   const int kind = nr.idx == PT_END ? 0 : ((nr.idx & PT_LIGHT) ? 2 : 1);
   const int index = kind == 0 ? -1 : (int)(nr.idx & ~PT_LIGHT);

@@ -77,7 +77,8 @@ class TraceStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("mesh_hits", C.c_uint64), ("nmap_hits", C.c_uint64), ("samples", C.c_uint64),
                 ("wave_node_iters", C.c_uint64), ("wave_tri_iters", C.c_uint64),
-                ("fetch_events", C.c_uint64), ("fetch_rays", C.c_uint64)]
+                ("fetch_events", C.c_uint64), ("fetch_rays", C.c_uint64),
+                ("idle_unstarted", C.c_uint64), ("idle_finished", C.c_uint64), ("idle_parked", C.c_uint64)]
 
 
 class SceneInfo(C.Structure):

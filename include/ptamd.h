@@ -224,6 +224,10 @@ typedef struct {
   uint64_t wave_tri_iters;  /* wave-level executions of the triangle-test loop body */
   uint64_t fetch_events;    /* split kernel: wave-level ray fetches by traverser waves */
   uint64_t fetch_rays;      /* split kernel: rays handed out by those fetches */
+  /* idle lane-slots of the box-test loop (64 * wave_node_iters = nodes_visited + these three), tile kernel: */
+  uint64_t idle_unstarted;  /* lane traces no ray in this call (path ended earlier, or outside the frame) */
+  uint64_t idle_finished;   /* lane's walk is over, the wave is still walking */
+  uint64_t idle_parked;     /* lane left the current box phase (holds a leaf / just finished) */
 } ptamd_trace_stats;
 
 /* Renders like ptamd_raytrace_ex with an instrumented build of the selected kernel and

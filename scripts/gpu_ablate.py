@@ -36,4 +36,4 @@ for name, kern in (("tile", P.KERNEL_BVH), ("blockwise", P.KERNEL_BVH_BLOCKWISE)
     ms, s = timeit(indoor, sid_i, 1, kern, moved=True); print(f"{name:10s} indoor moved(preview): {ms:.4f} ms/launch rays {s['rays']} nodes/ray {s['nodes_visited']/max(s['rays'],1):.2f}")
     for B in (1, 2, 3, 4, 8):
         ms, s = timeit(indoor, sid_i, B, kern)
-        print(f"{name:10s} indoor B={B}: {ms:.4f} ms/launch  rays {s['rays']} (mesh hits {s['mesh_hits']}) nodes/ray {s['nodes_visited']/max(s['rays'],1):.2f} tris/ray {s['tris_tested']/max(s['rays'],1):.2f} node-lane-util {s['nodes_visited']/max(64*s['wave_node_iters'],1):.3f} tri-lane-util {s['tris_tested']/max(64*s['wave_tri_iters'],1):.3f} wave-iters node {s['wave_node_iters']} tri {s['wave_tri_iters']}", flush=True)
+        print(f"{name:10s} indoor B={B}: {ms:.4f} ms/launch  rays {s['rays']} (mesh hits {s['mesh_hits']}) nodes/ray {s['nodes_visited']/max(s['rays'],1):.2f} tris/ray {s['tris_tested']/max(s['rays'],1):.2f} node-lane-util {s['nodes_visited']/max(64*s['wave_node_iters'],1):.3f} tri-lane-util {s['tris_tested']/max(64*s['wave_tri_iters'],1):.3f} wave-iters node {s['wave_node_iters']} tri {s['wave_tri_iters']} idle-slot shares: unstarted {s['idle_unstarted']/max(64*s['wave_node_iters'],1):.3f} finished {s['idle_finished']/max(64*s['wave_node_iters'],1):.3f} parked {s['idle_parked']/max(64*s['wave_node_iters'],1):.3f}", flush=True)

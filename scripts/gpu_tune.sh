@@ -1,12 +1,8 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
-run() { timeout -k 10 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>>$OUT/bench.err | python -c "
+run() { timeout -k 10 120 python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" 2>>$OUT/bench.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('$LABEL', d['config']['kernel'], d['value'], 'Msamples/s', d['ms_per_frame'], 'ms/frame', d['rgba_checksum_rank0_band'])"; }
-for lm in 64 48 32 24 16 8; do
-  rm -f cuda-pathtracer_amd/libptamd.so; make -s lib EXTRA_HIPFLAGS="-DPT_LEAF_MIN=${lm}u" 2>&1 | grep -E "error"
-  LABEL="leafmin$lm" run --kernel persistent
-  timeout -k 10 60 python scripts/gpu_ablate.py 2>&1 | grep "tile       indoor B=4"
-done
-rm -f cuda-pathtracer_amd/libptamd.so; make -s lib 2>&1 | grep error; true
+print('$LABEL', d['value'], 'Msamples/s', d['ms_per_frame'], 'ms/frame')"; }
+for b in 3 5 6; do for rm in 64 16; do LABEL="B$b-refill$rm" PTAMD_REFILL_MIN=$rm run --kernel persistent --bounces $b; done; done
+for rm in 64 16; do LABEL="C5-refill$rm" PTAMD_REFILL_MIN=$rm run --kernel persistent --width 3840 --height 2160 --spp 16 --bounces 8 --aperture 0.113 --steps 3 --warmup 1; done
