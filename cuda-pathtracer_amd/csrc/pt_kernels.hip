@@ -756,8 +756,7 @@ __global__ void __launch_bounds__(BLOCK, PT_TILE_WAVES_PER_EU) pt_megakernel(con
   // BLOCK/64 waves as a 2 x (BLOCK/128) grid of 8x8 tiles: the block covers 16 x (BLOCK/16) pixels
   const uint32_t x = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
   const uint32_t y = p.row_begin + blockIdx.y * (BLOCK / 16u) + (wave >> 1) * 8u + (lane >> 3);
-  Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
+  Counters cnt = {};
   const bool active = x < p.width && y < p.row_end;
   if (active) {
     Path st;
@@ -785,8 +784,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
   stage_scene<KIND, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris);
 
   const uint32_t lane = threadIdx.x & 63u;
-  Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
+  Counters cnt = {};
   uint32_t samples = 0;
 
   Path st;
@@ -896,8 +894,7 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
   uint32_t* s_ticket = s_cnt + 129;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
+  Counters cnt = {};
   uint32_t samples = 0;
   uint32_t ticket = blockIdx.x; // first super-tile is static, later ones come from the counter
 
@@ -1061,8 +1058,7 @@ __global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakern
   if (tid == 0) *fin = 0u;
   __syncthreads(); // the only barrier: control words initialised (stage_scene's barrier came before the stores)
 
-  Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
+  Counters cnt = {};
   uint32_t samples = 0;
   const uint32_t spin_limit = 1u << 26; // bounded spins: a protocol bug must not hang the GPU
 
@@ -1236,8 +1232,7 @@ __global__ void __launch_bounds__(256) pt_trace_rays_kernel(const KParams p, con
   if (i >= n) return;
   const f3 d = mk3(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]);
   const f3 o = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
-  Counters cnt;
-  cnt.rays = cnt.nodes = cnt.tris = cnt.mesh_hits = cnt.nmap_hits = cnt.wave_node_iters = cnt.wave_tri_iters = cnt.fetch_events = cnt.fetch_rays = cnt.idle3[0] = cnt.idle3[1] = cnt.idle3[2] = 0;
+  Counters cnt = {};
   const Nearest nr = trace_nearest<KIND, false>(p, p.nodes, KIND == 1 ? p.tris_brute : p.tris_bvh, o, d, cnt);
   const int kind = nr.idx == PT_END ? 0 : ((nr.idx & PT_LIGHT) ? 2 : 1);
   const int index = kind == 0 ? -1 : (int)(nr.idx & ~PT_LIGHT);
