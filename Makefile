@@ -7,7 +7,7 @@ ARCH     ?= gfx950
 HIPFLAGS := $(EXTRA_HIPFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/host -I$(PKG)/csrc \
             -Wall -Wextra -Wno-unused-parameter
 LIB      := $(PKG)/libptamd.so
-SRCS     := $(PKG)/csrc/pt_kernels.hip $(PKG)/csrc/ptamd_api.cpp $(PKG)/host/scene_loader.cpp $(PKG)/host/bvh_builder.cpp
+SRCS     := $(PKG)/csrc/pt_kernels.hip $(PKG)/csrc/ptamd_api.cpp $(PKG)/host/scene_loader.cpp $(PKG)/host/bvh_builder.cpp $(PKG)/host/image_decode.cpp
 HDRS     := include/ptamd.h $(PKG)/host/ptamd_internal.h $(PKG)/csrc/pt_device.h $(PKG)/csrc/pt_launch.h
 
 ORACLE   := oracle/libpt_oracle.so
@@ -22,7 +22,23 @@ $(LIB): $(SRCS) $(HDRS)
 $(ORACLE): oracle/pt_oracle.c oracle/pt_oracle.h
 	gcc -O2 -std=c11 -ffp-contract=off -mfma -fPIC -shared -Wall -Wextra -o $@ oracle/pt_oracle.c -lm -lpthread
 
-clean:
-	rm -f $(LIB) $(ORACLE)
+# oracle/_ref: the third-party libraries the reference vendors for the input side of the path (tinyobj,
+# stb_image, stb_image_resize), compiled from where they lie under /root/reference.  Test infrastructure only;
+# built only where the reference is present (the GPU box receives the prebuilt .so with the snapshot).
+REFERENCE ?= /root/reference
+REF3P_INC := $(REFERENCE)/cuda_opengl/3rd_party/include
+REFLIB    := oracle/_ref/libref_thirdparty.so
+ifneq ($(wildcard $(REF3P_INC)/tiny_obj_loader.h),)
+oracle-ref: $(REFLIB)
+$(REFLIB): oracle/ref_thirdparty.cpp
+	@mkdir -p oracle/_ref
+	g++ -O2 -std=c++11 -fPIC -shared -w -I$(REF3P_INC) -o $@ $<
+else
+oracle-ref:
+	@echo "oracle-ref: $(REF3P_INC) not present, skipped"
+endif
 
-.PHONY: all lib oracle clean
+clean:
+	rm -f $(LIB) $(ORACLE) $(REFLIB)
+
+.PHONY: all lib oracle oracle-ref clean

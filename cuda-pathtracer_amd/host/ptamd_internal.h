@@ -30,7 +30,17 @@ struct ImageProvider {
   void* user;
 };
 
+// provider == nullptr: the built-in decoder (image_decode.cpp) unless flags bit 1 (PTAMD_LOAD_NO_IMAGES) is set.
 int load_host_scene(const char* scene_path, uint32_t flags, const ImageProvider* provider, HostScene*& out);
+
+// ---- built-in image decoding (image_decode.cpp): JPEG, bit-identical to the reference's stb_image 2.16
+struct Image8 { int w = 0, h = 0, c = 0; std::vector<uint8_t> px; };
+bool decode_jpeg(const uint8_t* bytes, size_t n_bytes, Image8& img, std::string& err);
+bool load_image8(const char* path, Image8& img, std::string& err);
+// stbi_loadf(path, &w, &h, &c, STBI_default): *data is malloc'd, free with std::free / ptamd_image_free
+bool load_image_float(const char* path, int* w, int* h, int* c, float** data, std::string& err);
+const float* ldr_to_linear_table();
+const ImageProvider* builtin_image_provider();
 
 // ---- BVH (bvh_builder.cpp) -----------------------------------------------------------
 //

@@ -11,11 +11,13 @@
 //   Face flattening ....... scene.cpp:218-262 (AoS Face, per-face tangent)
 //   Materials/textures .... material_loader.cpp:164-401 (diffuse rgb + specular a packed
 //                           into one RGBA float texture, 1x1 fallbacks, global texture ids)
-// Image DECODING is injected by the caller (ptamd_host_scene_load_ex), as stb_image is a vendored
-// third party for the reference; without a provider every texture file "fails to load", which is
-// exactly what happens to indoor.mtl's backslash paths in the reference on Linux
-// (material_loader.cpp:97-104).  This is written from scratch; nothing here is taken from
-// tinyobjloader or stb.
+// Image decoding goes through an ImageProvider (default: the built-in decoder of image_decode.cpp);
+// a file that cannot be opened "fails to load", which is exactly what happens to indoor.mtl's
+// backslash paths in the reference on Linux (material_loader.cpp:97-104).
+// The lexical rules that decide VALUES are tinyobj's, restated: its own decimal reader (not strtod),
+// its line splitting, its texture-option grammar, its material flushing.  tests/test_ref_thirdparty.py
+// checks this parser against the real tinyobj 1.0.8 compiled from /root/reference (oracle/_ref) on the
+// shipped assets and on fuzzed OBJ/MTL text; the outputs must be bit-identical.
 #include "ptamd_internal.h"
 
 #include <cmath>
@@ -99,59 +101,114 @@ const char* skip_ws(const char* p)
 bool is_space(char c) { return c == ' ' || c == '\t'; }
 bool is_eol(char c) { return c == '\0' || c == '\r' || c == '\n'; }
 
-// decimal text -> float through double, as a real_t=float tinyobj build does
-float parse_real(const char*& p, float fallback = 0.0f)
+bool is_digit(char c) { return (unsigned)(c - '0') < 10u; }
+
+// tinyobj's own decimal reader (tiny_obj_loader.h:498-611), restated because it, not strtod, defines
+// the vertex bits: sign, digits accumulated as m = m * 10 + d, fraction digits added as
+// d * 10^-k (table for k < 8, pow beyond), optional exponent applied as ldexp(m * 5^e, e).
+// Greedy: stops at the first character outside the grammar.  No leading '.', no inf/nan, no hex.
+bool parse_decimal(const char* s, const char* end, double& out)
 {
-  p = skip_ws(p);
-  if (is_eol(*p)) return fallback;
-  char* end = nullptr;
-  double v = std::strtod(p, &end);
-  if (end == p) {
-    p += std::strcspn(p, " \t\r");
-    return fallback;
+  static const double kNegPow10[8] = { 1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001 };
+  if (s >= end) return false;
+  const char* c = s;
+  bool negative = false;
+  if (*c == '+' || *c == '-') { negative = (*c == '-'); ++c; }
+  else if (!is_digit(*c)) return false;
+  double mantissa = 0.0;
+  int n_int = 0;
+  for (; c != end && is_digit(*c); ++c, ++n_int) { mantissa *= 10; mantissa += (int)(*c - '0'); }
+  if (n_int == 0) return false;
+  int exp10 = 0;
+  if (c != end && (*c == '.' || *c == 'e' || *c == 'E')) {
+    if (*c == '.') {
+      ++c;
+      for (int k = 1; c != end && is_digit(*c); ++c, ++k)
+        mantissa += (int)(*c - '0') * (k < 8 ? kNegPow10[k] : std::pow(10.0, (double)-k));
+    }
+    if (c != end && (*c == 'e' || *c == 'E')) {
+      ++c;
+      bool exp_negative = false;
+      if (c != end && (*c == '+' || *c == '-')) { exp_negative = (*c == '-'); ++c; }
+      else if (!is_digit(*c)) return false;          // "1e" / "1ex": the whole number is rejected
+      int n_exp = 0;
+      for (; c != end && is_digit(*c); ++c, ++n_exp) exp10 = exp10 * 10 + (int)(*c - '0');
+      if (exp_negative) exp10 = -exp10;
+      if (n_exp == 0) return false;
+    }
   }
+  const double v = exp10 ? std::ldexp(mantissa * std::pow(5.0, (double)exp10), exp10) : mantissa;
+  out = negative ? -v : v;
+  return true;
+}
+
+// parseReal (tiny_obj_loader.h:613-621): always consumes one blank-delimited token, parsed or not
+float parse_real(const char*& p, double fallback = 0.0)
+{
+  p += std::strspn(p, " \t");
+  const char* end = p + std::strcspn(p, " \t\r");
+  double v = fallback;
+  parse_decimal(p, end, v);
   p = end;
   return (float)v;
 }
 
-std::string rest_of_line(const char* p)
+void skip_token(const char*& p)
 {
-  std::string s(p);
-  while (!s.empty() && (s.back() == '\r' || s.back() == '\n')) s.pop_back();
-  return s;
+  p += std::strspn(p, " \t");
+  p += std::strcspn(p, " \t\r");
 }
 
-// texture statement: options (-bm 1.0, -s u v w, ...) precede the file name
+// safeGetline (tiny_obj_loader.h:392-423): lines end at "\n", "\r\n" or a lone "\r"
+bool read_lines(const std::string& path, std::vector<std::string>& lines)
+{
+  std::ifstream f(path.c_str(), std::ios::binary);
+  if (!f) return false;
+  std::string text;        // a path that opens but cannot be read (a directory) reads as empty, as it does for tinyobj
+  char buf[1 << 16];
+  while (f.read(buf, sizeof buf) || f.gcount() > 0) text.append(buf, (size_t)f.gcount());
+  std::string cur;
+  for (size_t i = 0; i < text.size(); ++i) {
+    const char c = text[i];
+    if (c == '\n' || c == '\r') {
+      if (c == '\r' && i + 1 < text.size() && text[i + 1] == '\n') ++i;
+      lines.push_back(cur);
+      cur.clear();
+    } else cur += c;
+  }
+  if (!cur.empty()) lines.push_back(cur);
+  return true;
+}
+
+bool option(const char* p, const char* kw)
+{
+  size_t n = std::strlen(kw);
+  return std::strncmp(p, kw, n) == 0 && is_space(p[n]);
+}
+
+// ParseTextureNameAndOption (tiny_obj_loader.h:833-918).  Known options swallow a FIXED number of
+// tokens whatever those tokens are (`-s 1 2 tex.jpg` eats the file name); anything else is a file name,
+// and the last file name on the line wins.
 std::string parse_texture_name(const char* p)
 {
   std::string name;
   while (!is_eol(*p)) {
-    p = skip_ws(p);
-    if (is_eol(*p)) break;
-    if (*p == '-') {
-      // option: skip its keyword and numeric/on-off arguments
-      const char* kw = p;
-      p += std::strcspn(p, " \t\r");
-      std::string key(kw, p);
-      int nargs = 1;
-      if (key == "-o" || key == "-s" || key == "-t") nargs = 3;
-      else if (key == "-mm") nargs = 2;
-      for (int i = 0; i < nargs; ++i) {
-        p = skip_ws(p);
-        if (is_eol(*p)) break;
-        // -o/-s/-t take up to 3 numbers; stop early on a non-number
-        if (nargs == 3 && i > 0) {
-          char* e = nullptr;
-          std::strtod(p, &e);
-          if (e == p) break;
-        }
-        p += std::strcspn(p, " \t\r");
-      }
+    p += std::strspn(p, " \t");
+    int eat = -1;
+    if (option(p, "-blendu") || option(p, "-blendv")) { p += 8; eat = 1; }
+    else if (option(p, "-clamp") || option(p, "-boost")) { p += 7; eat = 1; }
+    else if (option(p, "-bm") || option(p, "-mm")) { eat = (p[1] == 'm') ? 2 : 1; p += 4; }
+    else if (option(p, "-o") || option(p, "-s") || option(p, "-t")) { p += 3; eat = 3; }
+    else if (option(p, "-type")) { p += 5; eat = 1; }
+    else if (option(p, "-imfchan")) { p += 9; eat = 1; }
+    if (eat >= 0) {
+      for (int i = 0; i < eat; ++i) skip_token(p);
       continue;
     }
     size_t n = std::strcspn(p, " \t\r");
     name.assign(p, n);
     p += n;
+    p += std::strspn(p, " \t");
   }
   return name;
 }
@@ -162,30 +219,27 @@ bool starts(const char* p, const char* kw)
   return std::strncmp(p, kw, n) == 0 && is_space(p[n]);
 }
 
+// LoadMtl (tiny_obj_loader.h:1010-1393).  A material is flushed when the next `newmtl` arrives and its name
+// is not empty; the LAST one is flushed unconditionally, so a file without any `newmtl` (or an mtllib name
+// that opens but yields no line, e.g. a directory) still contributes one default material named "".
 bool load_mtl(const std::string& path, std::vector<MtlEntry>& out, std::map<std::string, int>& index)
 {
-  std::ifstream f(path);
-  if (!f.is_open()) return false;
+  std::vector<std::string> lines;
+  if (!read_lines(path, lines)) return false;
   MtlEntry cur;
-  bool have = false;
-  auto flush = [&]() {
-    if (have && !cur.name.empty()) {
-      index.insert(std::make_pair(cur.name, (int)out.size()));
-      out.push_back(cur);
-    }
-  };
-  std::string line;
-  while (std::getline(f, line)) {
-    size_t last = line.find_last_not_of(" \t\r\n");
-    if (last == std::string::npos) continue;
-    line.erase(last + 1);
+  for (std::string& line : lines) {
+    size_t last = line.find_last_not_of(" \t");
+    line.erase(last == std::string::npos ? 0 : last + 1);
+    if (line.empty()) continue;
     const char* p = skip_ws(line.c_str());
     if (*p == '\0' || *p == '#') continue;
     if (starts(p, "newmtl")) {
-      flush();
+      if (!cur.name.empty()) {
+        index.insert(std::make_pair(cur.name, (int)out.size()));
+        out.push_back(cur);
+      }
       cur = MtlEntry();
-      cur.name = rest_of_line(p + 7);
-      have = true;
+      cur.name = p + 7;
     } else if (p[0] == 'K' && p[1] == 'd' && is_space(p[2])) {
       p += 2;
       cur.diffuse[0] = parse_real(p); cur.diffuse[1] = parse_real(p); cur.diffuse[2] = parse_real(p);
@@ -196,18 +250,24 @@ bool load_mtl(const std::string& path, std::vector<MtlEntry>& out, std::map<std:
       p += 2;
       cur.ior = parse_real(p);
     } else if (starts(p, "map_Kd")) {
-      cur.diffuse_tex = parse_texture_name(p + 7);
+      std::string n = parse_texture_name(p + 7);
+      if (!n.empty()) cur.diffuse_tex = n;
     } else if (starts(p, "map_Ks")) {
-      cur.specular_tex = parse_texture_name(p + 7);
+      std::string n = parse_texture_name(p + 7);
+      if (!n.empty()) cur.specular_tex = n;
     } else if (starts(p, "map_bump") || starts(p, "map_Bump")) {
-      cur.bump_tex = parse_texture_name(p + 9);
+      std::string n = parse_texture_name(p + 9);
+      if (!n.empty()) cur.bump_tex = n;
     } else if (starts(p, "bump")) {
-      cur.bump_tex = parse_texture_name(p + 5);
+      std::string n = parse_texture_name(p + 5);
+      if (!n.empty()) cur.bump_tex = n;
     } else if (starts(p, "norm")) {
-      cur.normal_tex = parse_texture_name(p + 5);
+      std::string n = parse_texture_name(p + 5);
+      if (!n.empty()) cur.normal_tex = n;
     }
   }
-  flush();
+  index.insert(std::make_pair(cur.name, (int)out.size()));
+  out.push_back(cur);
   return true;
 }
 
@@ -253,8 +313,8 @@ struct ObjData {
 
 bool load_obj(const std::string& path, const std::string& mtl_dir, ObjData& obj, std::string& err)
 {
-  std::ifstream f(path);
-  if (!f.is_open()) {
+  std::vector<std::string> lines;
+  if (!read_lines(path, lines)) {
     err = "cannot open OBJ '" + path + "'";
     return false;
   }
@@ -277,9 +337,7 @@ bool load_obj(const std::string& path, const std::string& mtl_dir, ObjData& obj,
     return true;
   };
 
-  std::string line;
-  while (std::getline(f, line)) {
-    while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+  for (const std::string& line : lines) {
     if (line.empty()) continue;
     const char* p = skip_ws(line.c_str());
     if (*p == '\0' || *p == '#') continue;
@@ -309,7 +367,7 @@ bool load_obj(const std::string& path, const std::string& mtl_dir, ObjData& obj,
       }
       group.push_back(std::move(poly));
     } else if (starts(p, "usemtl")) {
-      std::string name = rest_of_line(p + 7);
+      std::string name = p + 7;
       int id = -1;
       auto it = mtl_index.find(name);
       if (it != mtl_index.end()) id = it->second;
@@ -319,12 +377,12 @@ bool load_obj(const std::string& path, const std::string& mtl_dir, ObjData& obj,
         material = id;
       }
     } else if (starts(p, "mtllib")) {
-      std::stringstream ss(rest_of_line(p + 7));
+      // names split on single blanks, first file that opens wins (tiny_obj_loader.h:1617-1650); an empty
+      // name (two blanks in a row) is tried too, as tinyobj does: it opens the MTL directory itself
+      std::stringstream ss(std::string(p + 7));
       std::string fn;
-      while (std::getline(ss, fn, ' ')) {
-        if (fn.empty()) continue;
+      while (std::getline(ss, fn, ' '))
         if (load_mtl(mtl_dir + fn, obj.materials, mtl_index)) break;
-      }
     } else if (p[0] == 'g' && is_space(p[1])) {
       export_group();
       if (!shape.empty()) obj.shapes.push_back(shape);
@@ -346,10 +404,11 @@ bool load_obj(const std::string& path, const std::string& mtl_dir, ObjData& obj,
 
 // ---------------------------------------------------------------- materials and textures
 //
-// material_loader.cpp:164-401.  Image decoding is injected (ImageProvider): the reference gets
-// its float texels from stb_image's stbi_loadf (material_loader.cpp:97), a host application
-// passes an equivalent through ptamd_host_scene_load_ex.  Without a provider every image "fails
-// to load", which is what the reference does with indoor.mtl's backslash paths on Linux.
+// material_loader.cpp:164-401.  Image decoding goes through an ImageProvider: the reference gets
+// its float texels from stb_image's stbi_loadf (material_loader.cpp:97); here the default provider is
+// the built-in decoder of image_decode.cpp (same pixels), and a host application may pass its own
+// through ptamd_host_scene_load_ex.  A file that cannot be opened or decoded "fails to load", which
+// is what the reference does with indoor.mtl's backslash paths on Linux.
 
 namespace {
 
@@ -526,8 +585,24 @@ static bool build_faces(const ObjData& obj, HostScene& hs, std::string& err)
   return true;
 }
 
+static int builtin_load(void*, const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, float** data)
+{
+  std::string err; int iw = 0, ih = 0, ic = 0;
+  if (!load_image_float(path, &iw, &ih, &ic, data, err)) return 1;
+  *w = iw; *h = ih; *nb_chan = ic;
+  return 0;
+}
+static void builtin_release(void*, float* data) { std::free(data); }
+
+const ImageProvider* builtin_image_provider()
+{
+  static const ImageProvider prov{ builtin_load, builtin_release, nullptr };
+  return &prov;
+}
+
 int load_host_scene(const char* scene_path, uint32_t flags, const ImageProvider* provider, HostScene*& out)
 {
+  if (!provider && !(flags & PTAMD_LOAD_NO_IMAGES)) provider = builtin_image_provider();
   std::ifstream file(scene_path);
   if (!file.is_open()) {
     set_error(std::string("cannot open scene file '") + scene_path + "'");

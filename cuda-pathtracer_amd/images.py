@@ -1,11 +1,52 @@
-"""Image providers for the scene loader.  The reference decodes textures with stb_image's
+"""Image decoding for the scene loader.  The reference decodes textures with stb_image's
 stbi_loadf (material_loader.cpp:97, gpu_processor.cpp:99): 8-bit channels become floats through
 `pow(v / 255, 2.2)` for colour channels and `v / 255` for an alpha channel (stb_image.h: the
-ldr-to-hdr conversion).  `pil_image_loader` reproduces that contract on top of PIL's decoder; the
-decoders themselves (stb vs libjpeg) may differ by an LSB on JPEG data."""
+ldr-to-hdr conversion).
+
+`load_image` / `load_image8` call libptamd's built-in JPEG decoder (host/image_decode.cpp), whose
+pixels are bit-identical to stb_image's; it is what `HostScene.load` uses by default.
+`pil_image_loader` is an optional provider for formats the built-in decoder does not read (PNG ...):
+it reproduces the float contract on top of PIL, but PIL's JPEG decoder (libjpeg) differs from stb's
+by an LSB here and there, so it is not used for parity runs."""
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
+
+from . import native as N
+
+
+def load_image(path: str) -> np.ndarray:
+    """stbi_loadf(path, STBI_default): float32[h, w, c], c = 1 (grayscale file) or 3.  Raises on failure."""
+    w, h, c = C.c_int32(), C.c_int32(), C.c_int32()
+    data = C.POINTER(C.c_float)()
+    lib = N.load()
+    N.check(lib.ptamd_image_loadf(path.encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(data)))
+    try:
+        return np.ctypeslib.as_array(data, shape=(h.value, w.value, c.value)).copy()
+    finally:
+        lib.ptamd_image_free(data)
+
+
+def load_image8(path: str) -> np.ndarray:
+    """stbi_load(path, STBI_default): uint8[h, w, c]."""
+    w, h, c = C.c_int32(), C.c_int32(), C.c_int32()
+    data = C.POINTER(C.c_uint8)()
+    lib = N.load()
+    N.check(lib.ptamd_image_load8(path.encode(), C.byref(w), C.byref(h), C.byref(c), C.byref(data)))
+    try:
+        return np.ctypeslib.as_array(data, shape=(h.value, w.value, c.value)).copy()
+    finally:
+        lib.ptamd_image_free(data)
+
+
+def native_image_loader(path: str):
+    """`f(path) -> float32[h, w, c] | None` over the built-in decoder (for cubemap_for_scene)."""
+    try:
+        return load_image(path)
+    except (N.PtamdError, OSError):
+        return None
 
 
 def ldr_to_float(img8: np.ndarray) -> np.ndarray:

@@ -91,6 +91,7 @@ assert C.sizeof(Face) == 112 and C.sizeof(Material) == 16 and C.sizeof(Light) ==
 IMAGE_LOAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                             C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_float)))
 IMAGE_FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float))
+LOAD_FIX_BACKSLASHES, LOAD_NO_IMAGES = 1, 2   # ptamd_host_scene_load flags
 
 # name -> (restype, argtypes); every symbol include/ptamd.h declares
 SIGNATURES = {
@@ -99,6 +100,11 @@ SIGNATURES = {
     "ptamd_host_scene_load": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "ptamd_host_scene_load_ex": (C.c_int, [C.c_char_p, C.c_uint32, IMAGE_LOAD_FN, IMAGE_FREE_FN, C.c_void_p,
                                             C.POINTER(C.c_void_p)]),
+    "ptamd_image_loadf": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.POINTER(C.c_float))]),
+    "ptamd_image_load8": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.POINTER(C.c_uint8))]),
+    "ptamd_image_free": (None, [C.c_void_p]),
     "ptamd_host_scene_unloaded_count": (C.c_uint32, [C.c_void_p]),
     "ptamd_host_scene_unloaded_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "ptamd_host_scene_free": (None, [C.c_void_p]),

@@ -48,14 +48,17 @@ class HostScene:
         self.cubemap = cubemap
 
     @classmethod
-    def load(cls, scene_path: str, normalise_backslashes: bool = False, image_loader=None) -> "HostScene":
+    def load(cls, scene_path: str, normalise_backslashes: bool = False, image_loader=None,
+             decode_images: bool = True) -> "HostScene":
         """Parses a .scene file and the OBJ/MTL it names (ptamd_host_scene_load[_ex]).
 
-        image_loader: optional `f(path) -> float32[h, w, c] | None` with stbi_loadf semantics (see
-        images.pil_image_loader).  Without it every texture file "fails to load" (1x1 fallbacks)."""
+        Texture files are decoded by libptamd's built-in decoder (bit-identical to the reference's
+        stb_image); `decode_images=False` skips them (every texture degrades to its 1x1 constant).
+        image_loader: optional replacement `f(path) -> float32[h, w, c] | None` with stbi_loadf
+        semantics (see images.pil_image_loader)."""
         lib = N.load()
         h = C.c_void_p()
-        flags = 1 if normalise_backslashes else 0
+        flags = (N.LOAD_FIX_BACKSLASHES if normalise_backslashes else 0) | (0 if decode_images else N.LOAD_NO_IMAGES)
         if image_loader is None:
             N.check(lib.ptamd_host_scene_load(scene_path.encode(), flags, C.byref(h)))
         else:
@@ -144,8 +147,8 @@ def cubemap_for_scene(scene: HostScene, honour_hex: bool = False, asset_folder: 
                       image_loader=None) -> np.ndarray:
     """The cubemap the reference binds for this scene (gpu_processor.cpp:68-161).
 
-    With `asset_folder` and `image_loader` the cube-cross image `folder/name` is decoded and cut
-    into six faces when it is a valid cross (width/4 == height/3, power of two); any failure —
+    With `asset_folder` the cube-cross image `folder/name` is decoded (built-in decoder unless an
+    `image_loader` is given) and cut into six faces when it is a valid cross (width/4 == height/3, power of two); any failure —
     as for indoor.scene's missing garden.jpg — ends in the 1x1 fallback of colour 0x131b23
     (:128-132).  uploadCubemaps passes `folder + "/" + name` to uploadCubemap (:177-181), so the
     `path.empty() || isHexa(path)` arm (:89-93) is never taken by the reference: a `0xRRGGBB`
@@ -154,7 +157,9 @@ def cubemap_for_scene(scene: HostScene, honour_hex: bool = False, asset_folder: 
     name = scene.cubemap
     if honour_hex and name.startswith("0x") and len(name) > 2 and all(ch in "0123456789abcdefABCDEF" for ch in name[2:]):
         return cubemap_from_color(int(name, 16) & 0xFFFFFF)
-    if asset_folder is not None and image_loader is not None and name:
+    if asset_folder is not None and name:
+        if image_loader is None:
+            from .images import native_image_loader as image_loader
         try:
             img = image_loader(asset_folder + "/" + name)
             if img is not None:

@@ -111,12 +111,27 @@ const char* ptamd_version(void);
 
 typedef struct ptamd_host_scene ptamd_host_scene;
 
-/* Parses a .scene file and the OBJ/MTL it names.  flags: bit 0 = normalise '\\' to '/'
- * in MTL texture paths (default 0 = reference-on-Linux behaviour: such textures fail to
- * load and degrade to 1x1 constants, material_loader.cpp:97-104). */
+/* Parses a .scene file and the OBJ/MTL it names, decoding the textures the MTL names with the
+ * built-in decoder (ptamd_image_loadf below).  flags:
+ *   PTAMD_LOAD_FIX_BACKSLASHES  normalise '\\' to '/' in MTL texture paths (default off = reference-
+ *                               on-Linux behaviour: such textures fail to load and degrade to 1x1
+ *                               constants, material_loader.cpp:97-104)
+ *   PTAMD_LOAD_NO_IMAGES        do not open image files at all: every texture degrades to its 1x1 constant */
+#define PTAMD_LOAD_FIX_BACKSLASHES 1u
+#define PTAMD_LOAD_NO_IMAGES       2u
 int  ptamd_host_scene_load(const char* scene_path, uint32_t flags, ptamd_host_scene** out);
 
-/* Image decoding is injected, as stb_image is for the reference (material_loader.cpp:97 stbi_loadf):
+/* stbi_loadf(path, &w, &h, &nb_chan, STBI_default) replacement (material_loader.cpp:97,
+ * gpu_processor.cpp:99): decodes a JPEG (baseline / extended / progressive) to w*h*nb_chan floats,
+ * nb_chan = 1 for grayscale files and 3 otherwise, linearised the way stbi_loadf does it (colour
+ * channels pow(v/255, 2.2f) in single precision).  The 8-bit pixels are bit-identical to stb_image
+ * 2.16's (the reference's decoder): tests/test_ref_thirdparty.py.  Other formats: PTAMD_ERR_IO.
+ * ptamd_image_load8 returns the 8-bit pixels (stbi_load).  Free either buffer with ptamd_image_free. */
+int  ptamd_image_loadf(const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, float** data);
+int  ptamd_image_load8(const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, uint8_t** data);
+void ptamd_image_free(void* data);
+
+/* A host may inject its own decoder instead, as stb_image is for the reference (stbi_loadf):
  * `load` returns 0 and a w*h*nb_chan float buffer (already linearised the way stbi_loadf does it:
  * colour channels pow(v/255, 2.2), alpha v/255) or non-zero when the file cannot be decoded;
  * `release` frees that buffer.  With load == NULL this is ptamd_host_scene_load.  The loader then

@@ -45,14 +45,33 @@ def textured_scene():
     return hs, synthetic_cubemap(rng, 8)
 
 
+_inputs = {}
+
+
+def case_inputs(name):
+    """(HostScene, cubemap faces) of a case, as the reference would have them on Linux; cached per process."""
+    if name not in _inputs:
+        if name == "textured_64x64_spp2_b4":
+            _inputs[name] = textured_scene()
+        else:
+            _inputs[name] = _load(CASES[name][0])
+    return _inputs[name]
+
+
+def _load(scene):
+    # reference-on-Linux behaviour: textures with '/' paths decode (crate_land: 1024^2 maps + the
+    # field_with_house cube cross), indoor.mtl's '\\' paths and cube crosses that are not shipped in
+    # assets/ (garden.jpg never existed; water.jpg is not copied) end in the 1x1 fallbacks
+    hs = P.HostScene.load(os.path.join(ROOT, "assets", scene))
+    return hs, P.cubemap_for_scene(hs, asset_folder=os.path.join(ROOT, "assets"))
+
+
 def render_case(name):
+    hs, cube = case_inputs(name)
     if name == "textured_64x64_spp2_b4":
-        hs, cube = textured_scene()
         W, H, spp, B, moved, post = 64, 64, 2, 4, False, 0
     else:
-        scene, W, H, spp, B, moved, post = CASES[name]
-        hs = P.HostScene.load(os.path.join(ROOT, "assets", scene))
-        cube = P.cubemap_for_scene(hs)
+        _, W, H, spp, B, moved, post = CASES[name]
     acc, rgba = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), W, H,
                          spp=spp, bounces=B, moved=moved, post_id=post)
     return hs, cube, dict(W=W, H=H, spp=spp, bounces=B, moved=moved, post_id=post), acc, rgba

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import ASSETS, GOLDEN
-from golden.make_golden import ALL, CASES, textured_scene
+from golden.make_golden import ALL, case_inputs
 from helpers import make_scene, random_rays, random_soup, synthetic_cubemap
 
 pytestmark = pytest.mark.gpu
@@ -51,11 +51,7 @@ def kid(P, name):
 @pytest.mark.parametrize("name", ALL)
 def test_hip_equals_golden_and_oracle(P, O, gpu_ctx, name, kernel):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    if name.startswith("textured"):
-        hs, cube = textured_scene()
-    else:
-        hs = P.HostScene.load(os.path.join(ASSETS, CASES[name][0]))
-        cube = P.cubemap_for_scene(hs)
+    hs, cube = case_inputs(name)
     W, H, spp, B = int(g["W"]), int(g["H"]), int(g["spp"]), int(g["bounces"])
     acc, rgba = gpu_render(P, gpu_ctx, hs, cube, W, H, spp, B, kid(P, kernel), moved=bool(g["moved"]), post_id=int(g["post_id"]))
     assert_same(acc, rgba, g["accum"], g["rgba"], f"{name}/{kernel} vs golden")
@@ -109,8 +105,13 @@ def test_degenerate_scenes(P, O, gpu_ctx):
     cases["nan_tangent_nmap"] = make_scene(P, tris, uvs=uvs, materials=[(0, 1, 1.0)],
                                            textures=[np.float32([[[0.5, 0.6, 0.7, 0.3]]]), rng.uniform(0, 1, (4, 4, 3)).astype(np.float32)],
                                            lights=lights)
+    # black albedo: throughput 0 -> p = 0 -> throughput *= 1/0 = NaN -> clamp maps NaN to 1.0: white pixels
+    cases["black_albedo_nan"] = make_scene(P, random_soup(rng, 40, extent=1.2, size=0.9),
+                                           textures=[np.float32([[[0.0, 0.0, 0.0, 0.25]]])], lights=lights)
     for name, hs in cases.items():
         ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 40, 24, spp=2, bounces=4)
+        if name == "black_albedo_nan":
+            assert (ref[0] == 2.0).all(axis=2).sum() > 20      # pixels whose two samples both clamped NaN -> 1.0
         for kernel in KERNELS:
             acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 40, 24, 2, 4, kid(P, kernel))
             # NaN accumulators cannot occur (clamp maps NaN to 1.0, raytrace.cu:248), so bit compare is total
@@ -309,9 +310,10 @@ def test_config4_sponza_class_deep_bvh(P, O, gpu_ctx, indoor):
 
 def test_crate_land_with_real_textures_and_cubemap(P, O, gpu_ctx):
     """The reference scene that exercises sampleTexture on 1024^2 RGBA textures, normal mapping and
-    a bilinear 1024^2 cubemap (decoded through the injected image provider)."""
-    hs = P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"), image_loader=P.pil_image_loader)
-    cube = P.cubemap_for_scene(hs, asset_folder=ASSETS, image_loader=P.pil_image_loader)
+    a bilinear 1024^2 cubemap, decoded by the built-in decoder (== the reference's stb_image, test_ref_thirdparty)."""
+    hs = P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"))
+    cube = P.cubemap_for_scene(hs, asset_folder=ASSETS)
+    assert hs.unloaded_textures == []
     assert cube.shape[1] == 1024 and len(hs.texels) > 14_000_000
     ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 96, 54, spp=2, bounces=4)
     assert O.last_stats()["nmap_hits"] > 100

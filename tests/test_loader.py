@@ -267,11 +267,20 @@ def test_ldr_to_float_and_real_assets(P):
     np.testing.assert_allclose(f[0, 0, :3], [0.0, (128 / 255) ** 2.2, 1.0], rtol=1e-6)
     assert f[0, 0, 3] == np.float32(64) / np.float32(255)          # alpha stays linear
     assert P.ldr_to_float(np.array([[7]], dtype=np.uint8)).shape == (1, 1, 1)
-    hs = P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"), image_loader=P.pil_image_loader)
+    hs = P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"))          # built-in decoder
     assert hs.unloaded_textures == []
     assert [(t["w"], t["h"], t["nb_chan"]) for t in hs.textures] == [(1024, 1024, 4), (1024, 1024, 3)] * 2
     assert list(hs.materials["normal_map"]) == [1, 3]
-    cube = P.cubemap_for_scene(hs, asset_folder=ASSETS, image_loader=P.pil_image_loader)
+    cube = P.cubemap_for_scene(hs, asset_folder=ASSETS)
     assert cube.shape == (6, 1024, 1024, 4) and (cube[..., 3] == 0).all() and 0.05 < cube[..., :3].mean() < 0.9
-    # without a provider the same scene degrades to constants, like every scene did before
-    assert len(P.HostScene.load(os.path.join(ASSETS, "crate_land.scene")).texels) == 8
+    # an injected provider (PIL's libjpeg) gives the same layout; its pixels differ from stb's by a few LSB at most
+    hp = P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"), image_loader=P.pil_image_loader)
+    assert hp.textures.tolist() == hs.textures.tolist()
+    assert np.abs(hp.texels - hs.texels).max() < 0.05 and (hp.texels != hs.texels).any()
+    # with decoding off the same scene degrades to constants
+    assert len(P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"), decode_images=False).texels) == 8
+    # indoor.mtl names its textures with backslashes: not found on Linux (reference behaviour) unless normalised
+    ind = P.HostScene.load(os.path.join(ASSETS, "indoor.scene"), normalise_backslashes=True)
+    got = {(int(t["w"]), int(t["h"]), int(t["nb_chan"])) for t in ind.textures}
+    assert (512, 512, 4) in got and (512, 512, 3) in got        # wooden_planck/albedo_2.jpg, crack2.jpg (the two shipped here)
+    assert "textures\\parquet\\albedo_1.jpg" in ind.unloaded_textures
