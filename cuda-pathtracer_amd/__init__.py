@@ -15,6 +15,6 @@ from .render import (Context, FrameRenderer, host_bvh_trace, wang_hash, REFERENC
 from .tiles import row_bands, band_of_rank, BandGather
 from .synthetic import tessellate
 from .image import save_ppm, load_ppm
-from .images import pil_image_loader, ldr_to_float, load_image, load_image8, native_image_loader
+from .images import pil_image_loader, ldr_to_float, load_image, load_image8, native_image_loader, resize_float
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -40,6 +40,8 @@ bool load_image8(const char* path, Image8& img, std::string& err);
 // stbi_loadf(path, &w, &h, &c, STBI_default): *data is malloc'd, free with std::free / ptamd_image_free
 bool load_image_float(const char* path, int* w, int* h, int* c, float** data, std::string& err);
 const float* ldr_to_linear_table();
+// stbir_resize_float(in, w, h, 0, out, W, H, 0, channels) restated (image_resize.cpp)
+bool resize_float(const float* in, int in_w, int in_h, float* out, int out_w, int out_h, int channels);
 const ImageProvider* builtin_image_provider();
 
 // ---- BVH (bvh_builder.cpp) -----------------------------------------------------------

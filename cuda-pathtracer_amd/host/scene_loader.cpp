@@ -488,20 +488,15 @@ struct TextureBook {
     else if (a->nb_chan != 1) id = push_packed(rgb, nullptr, default_rgb, default_a);
     else if (rgb->w == a->w && rgb->h == a->h) id = push_packed(rgb, a, default_rgb, default_a);
     else {
-      // The reference rescales the smaller map with stb_image_resize (material_loader.cpp:350-375);
-      // that filter is not restated here: the smaller map is resampled with nearest texels.
+      // the smaller map is rescaled to the larger one's size with stbir_resize_float
+      // (material_loader.cpp:350-375; image_resize.cpp restates it bit for bit)
       const bool a_bigger = (long)a->w * a->h > (long)rgb->w * rgb->h;
       const Image& big = a_bigger ? *a : *rgb;
       const Image& small = a_bigger ? *rgb : *a;
       Image scaled;
       scaled.w = big.w; scaled.h = big.h; scaled.nb_chan = small.nb_chan;
       scaled.data.resize((size_t)big.w * big.h * small.nb_chan);
-      for (int y = 0; y < big.h; ++y)
-        for (int x = 0; x < big.w; ++x) {
-          const int sx = (int)((long)x * small.w / big.w), sy = (int)((long)y * small.h / big.h);
-          for (int c = 0; c < small.nb_chan; ++c)
-            scaled.data[((size_t)y * big.w + x) * small.nb_chan + c] = small.data[((size_t)sy * small.w + sx) * small.nb_chan + c];
-        }
+      resize_float(small.data.data(), small.w, small.h, scaled.data.data(), big.w, big.h, small.nb_chan);
       id = a_bigger ? push_packed(&scaled, a, default_rgb, default_a) : push_packed(rgb, &scaled, default_rgb, default_a);
     }
     packed[token] = id;

@@ -41,6 +41,18 @@ def load_image8(path: str) -> np.ndarray:
         lib.ptamd_image_free(data)
 
 
+def resize_float(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """stbir_resize_float with its defaults: float32[h, w, c] -> float32[out_h, out_w, c]."""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    h, w, c = img.shape
+    out = np.zeros((out_h, out_w, c), np.float32)
+    N.check(N.load().ptamd_image_resize_float(img.ctypes.data_as(C.POINTER(C.c_float)), w, h,
+                                              out.ctypes.data_as(C.POINTER(C.c_float)), out_w, out_h, c))
+    return out
+
+
 def native_image_loader(path: str):
     """`f(path) -> float32[h, w, c] | None` over the built-in decoder (for cubemap_for_scene)."""
     try:

@@ -130,6 +130,11 @@ int  ptamd_host_scene_load(const char* scene_path, uint32_t flags, ptamd_host_sc
 int  ptamd_image_loadf(const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, float** data);
 int  ptamd_image_load8(const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, uint8_t** data);
 void ptamd_image_free(void* data);
+/* stbir_resize_float(in, in_w, in_h, 0, out, out_w, out_h, 0, channels) replacement (material_loader.cpp:358,367):
+ * the rescale applied when a material's diffuse and specular maps differ in size.  Bit-identical to
+ * stb_image_resize 0.95 (Catmull-Rom on growing axes, Mitchell otherwise, clamped edges). */
+int  ptamd_image_resize_float(const float* in, int32_t in_w, int32_t in_h, float* out, int32_t out_w, int32_t out_h,
+                              int32_t channels);
 
 /* A host may inject its own decoder instead, as stb_image is for the reference (stbi_loadf):
  * `load` returns 0 and a w*h*nb_chan float buffer (already linearised the way stbi_loadf does it:

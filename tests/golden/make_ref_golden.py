@@ -7,6 +7,7 @@ they lie under /root/reference).  The fixture holds only outputs (digests and bi
   ldr_to_linear_bits    stbi_loadf's float for each 8-bit level (its pow(v/255, 2.2f); level-exact gray JPEGs)
   obj[name]             sha256 of tinyobj::LoadObj's output flattened as scene.cpp:218-262 does, per shipped OBJ
   decimal_bits          float bits tinyobj's decimal reader produces for DECIMAL_SPELLINGS
+  resize_sha256         sha256 over stbir_resize_float's outputs for the seeded cases of test_ref_thirdparty.resize_cases
 
 so that the loader / decoder stay pinned where /root/reference is absent (tests/test_ref_thirdparty.py).
 """
@@ -109,6 +110,12 @@ if __name__ == "__main__":
         xs = d["vertices"].reshape(-1, 3)[:, 0]
         assert len(xs) == len(DECIMAL_SPELLINGS)
         out["decimal_bits"] = [int(b) for b in xs.view(np.uint32)]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_ref_thirdparty import resize_cases
+    h = hashlib.sha256()
+    for img, ow, oh in resize_cases():
+        h.update(R.stbir_resize_float(img, ow, oh).tobytes())
+    out["resize_sha256"] = h.hexdigest()
     with open(os.path.join(HERE, "ref_thirdparty.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote ref_thirdparty.json:", len(out["jpeg"]), "jpegs,", len(out["obj"]), "objs,", len(out["decimal_bits"]), "decimals;",

@@ -14,6 +14,7 @@ Where the library is absent (no /root/reference) the live tests skip and the com
 tests/golden/ref_thirdparty.json (generated from it by tests/golden/make_ref_golden.py) is what pins the
 same code paths.
 """
+import hashlib
 import io
 import json
 import os
@@ -265,6 +266,41 @@ def test_reference_libm_float_conversion_table(P, tmp_path):
     np.testing.assert_array_equal(m8, a8)
     np.testing.assert_array_equal(mf.view(np.uint32), af.view(np.uint32))
     assert len(np.unique(a8)) > 200
+
+
+# ------------------------------------------------------------------ stbir_resize_float
+
+def resize_cases():
+    """Seeded (image, out_w, out_h) triples: growing, shrinking, mixed and equal axes, single rows/columns, 1 and 3 channels."""
+    rng = np.random.default_rng(11)
+    fixed = [(4, 4, 8, 8), (8, 8, 4, 4), (5, 7, 11, 13), (16, 9, 7, 20), (10, 10, 10, 20), (10, 10, 20, 10), (1, 1, 5, 5), (5, 5, 1, 1),
+             (2, 9, 9, 2), (32, 32, 33, 31), (64, 16, 16, 64), (13, 1, 40, 1), (1, 13, 1, 40), (9, 9, 10, 10), (10, 10, 9, 9), (3, 200, 200, 3)]
+    rnd = [tuple(int(v) for v in rng.integers(1, 70, size=4)) for _ in range(60)]
+    for i, (iw, ih, ow, oh) in enumerate(fixed + rnd):
+        if (iw, ih) == (ow, oh):
+            continue
+        c = 1 if i % 2 else 3
+        img = rng.uniform(-0.5, 1.5, size=(ih, iw, c)).astype(np.float32) * np.float32(10.0 ** int(rng.integers(-3, 3)))
+        yield img, ow, oh
+
+
+@live
+def test_resize_matches_stbir(P):
+    n = 0
+    for img, ow, oh in resize_cases():
+        np.testing.assert_array_equal(P.resize_float(img, ow, oh).view(np.uint32), R.stbir_resize_float(img, ow, oh).view(np.uint32),
+                                      err_msg="%s -> %dx%d" % (img.shape, ow, oh))
+        n += 1
+    assert n > 70
+    big = np.random.default_rng(1).uniform(0, 1, size=(256, 128, 1)).astype(np.float32)       # a specular map grown to its albedo's size
+    np.testing.assert_array_equal(P.resize_float(big, 512, 512).view(np.uint32), R.stbir_resize_float(big, 512, 512).view(np.uint32))
+
+
+def test_fixture_resize_digest(P, fixture):
+    h = hashlib.sha256()
+    for img, ow, oh in resize_cases():
+        h.update(P.resize_float(img, ow, oh).tobytes())
+    assert h.hexdigest() == fixture["resize_sha256"]
 
 
 # ------------------------------------------------------------------ without the reference: committed fixture + robustness
