@@ -14,7 +14,7 @@ from .render import (Context, FrameRenderer, host_bvh_trace, wang_hash, REFERENC
                      POST_NONE, POST_GRAYSCALE, POST_SEPIA, POST_INVERT)
 from .tiles import row_bands, band_of_rank, BandGather
 from .synthetic import tessellate
-from .image import save_ppm, load_ppm
+from .image import save_ppm, load_ppm, save_png
 from .images import pil_image_loader, ldr_to_float, load_image, load_image8, native_image_loader, resize_float
 
 __all__ = [n for n in dir() if not n.startswith("_")]

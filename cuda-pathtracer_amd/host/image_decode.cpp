@@ -16,8 +16,8 @@
 // layouts) against the real stb_image compiled from /root/reference into oracle/_ref; tests/golden holds the
 // checksums for where /root/reference is absent.
 //
-// Other formats stb_image reads (PNG, BMP, TGA, GIF, PSD, PIC, PNM, HDR) are reported as undecodable; a host
-// that needs them passes its own decoder through ptamd_host_scene_load_ex.
+// PNG is decoded by image_png.cpp.  The other formats stb_image reads (BMP, TGA, GIF, PSD, PIC, PNM, HDR) are
+// reported as undecodable; a host that needs them passes its own decoder through ptamd_host_scene_load_ex.
 #include "ptamd_internal.h"
 
 #include <cmath>
@@ -621,7 +621,9 @@ bool load_image8(const char* path, Image8& img, std::string& err) {
   std::vector<uint8_t> bytes;
   if (!read_file(path, bytes)) { err = "can't open file"; return false; }
   if (bytes.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) return decode_jpeg(bytes.data(), bytes.size(), img, err);
-  err = "unsupported image format (the built-in decoder reads JPEG; pass a decoder through ptamd_host_scene_load_ex)";
+  if (bytes.size() >= 8 && bytes[0] == 0x89 && bytes[1] == 'P' && bytes[2] == 'N' && bytes[3] == 'G')
+    return decode_png(bytes.data(), bytes.size(), img, err);
+  err = "unsupported image format (the built-in decoder reads JPEG and PNG; pass a decoder through ptamd_host_scene_load_ex)";
   return false;
 }
 
@@ -629,13 +631,9 @@ bool load_image8(const char* path, Image8& img, std::string& err) {
 // pow(v / 255, 2.2) evaluated in single precision (a C++ translation unit resolves pow(float, float) to the float
 // overload, as the reference's gpu_processor.cpp does); the last channel of 2- and 4-channel images is alpha, v / 255.
 const float* ldr_to_linear_table() {
-  static float table[256];
-  static bool ready = false;
-  if (!ready) {
-    for (int v = 0; v < 256; ++v) table[v] = (float)(std::pow((float)v / 255.0f, 2.2f) * 1.0f);
-    ready = true;
-  }
-  return table;
+  struct Table { float v[256]; Table() { for (int i = 0; i < 256; ++i) v[i] = (float)(std::pow((float)i / 255.0f, 2.2f) * 1.0f); } };
+  static const Table table;      // thread-safe one-time initialisation
+  return table.v;
 }
 
 bool load_image_float(const char* path, int* w, int* h, int* c, float** data, std::string& err) {

@@ -36,6 +36,8 @@ int load_host_scene(const char* scene_path, uint32_t flags, const ImageProvider*
 // ---- built-in image decoding (image_decode.cpp): JPEG, bit-identical to the reference's stb_image 2.16
 struct Image8 { int w = 0, h = 0, c = 0; std::vector<uint8_t> px; };
 bool decode_jpeg(const uint8_t* bytes, size_t n_bytes, Image8& img, std::string& err);
+bool decode_png(const uint8_t* bytes, size_t n_bytes, Image8& img, std::string& err);   // image_png.cpp
+bool encode_png(const uint8_t* pixels, int w, int h, int channels, std::vector<uint8_t>& out);
 bool load_image8(const char* path, Image8& img, std::string& err);
 // stbi_loadf(path, &w, &h, &c, STBI_default): *data is malloc'd, free with std::free / ptamd_image_free
 bool load_image_float(const char* path, int* w, int* h, int* c, float** data, std::string& err);

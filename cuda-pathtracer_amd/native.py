@@ -105,6 +105,7 @@ SIGNATURES = {
     "ptamd_image_load8": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                     C.POINTER(C.POINTER(C.c_uint8))]),
     "ptamd_image_free": (None, [C.c_void_p]),
+    "ptamd_image_save_png": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32]),
     "ptamd_image_resize_float": (C.c_int, [C.POINTER(C.c_float), C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.c_int32,
                                            C.c_int32]),
     "ptamd_host_scene_unloaded_count": (C.c_uint32, [C.c_void_p]),

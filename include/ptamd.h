@@ -122,14 +122,18 @@ typedef struct ptamd_host_scene ptamd_host_scene;
 int  ptamd_host_scene_load(const char* scene_path, uint32_t flags, ptamd_host_scene** out);
 
 /* stbi_loadf(path, &w, &h, &nb_chan, STBI_default) replacement (material_loader.cpp:97,
- * gpu_processor.cpp:99): decodes a JPEG (baseline / extended / progressive) to w*h*nb_chan floats,
- * nb_chan = 1 for grayscale files and 3 otherwise, linearised the way stbi_loadf does it (colour
- * channels pow(v/255, 2.2f) in single precision).  The 8-bit pixels are bit-identical to stb_image
+ * gpu_processor.cpp:99): decodes a JPEG (baseline / extended / progressive) or a PNG (every colour type, bit depth
+ * and interlace mode) to w*h*nb_chan floats, nb_chan as stb_image reports it (JPEG: 1 for grayscale files and 3
+ * otherwise; PNG: 1..4), linearised the way stbi_loadf does it (colour
+ * channels pow(v/255, 2.2f) in single precision, the alpha of 2- and 4-channel images v/255).  The 8-bit pixels are bit-identical to stb_image
  * 2.16's (the reference's decoder): tests/test_ref_thirdparty.py.  Other formats: PTAMD_ERR_IO.
  * ptamd_image_load8 returns the 8-bit pixels (stbi_load).  Free either buffer with ptamd_image_free. */
 int  ptamd_image_loadf(const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, float** data);
 int  ptamd_image_load8(const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, uint8_t** data);
 void ptamd_image_free(void* data);
+/* Writes 8-bit pixels (1 = gray, 2 = gray+alpha, 3 = RGB, 4 = RGBA; row 0 = top) as an uncompressed PNG: the
+ * image-output helper for a headless host (the reference only ever presents through GL). */
+int  ptamd_image_save_png(const char* path, const uint8_t* pixels, int32_t w, int32_t h, int32_t channels);
 /* stbir_resize_float(in, in_w, in_h, 0, out, out_w, out_h, 0, channels) replacement (material_loader.cpp:358,367):
  * the rescale applied when a material's diffuse and specular maps differ in size.  Bit-identical to
  * stb_image_resize 0.95 (Catmull-Rom on growing axes, Mitchell otherwise, clamped edges). */

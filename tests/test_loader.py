@@ -181,6 +181,27 @@ def test_ppm_roundtrip(P, tmp_path):
         P.save_ppm(str(tmp_path / "y.ppm"), img.astype(np.float32))
 
 
+def test_png_writer_roundtrip(P, tmp_path):
+    """ptamd_image_save_png -> the built-in PNG reader and PIL both give the pixels back; 4-channel surfaces drop alpha by default."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    path = str(tmp_path / "w.png")
+    for shape in ((1, 1, 3), (37, 53, 4), (5, 7, 1), (9, 3, 2), (300, 250, 3)):          # the last one spans several stored blocks
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        P.save_png(path, a, drop_alpha=False)
+        np.testing.assert_array_equal(P.load_image8(path), a)
+        with Image.open(path) as im:
+            im.load()
+            np.testing.assert_array_equal(np.asarray(im).reshape(shape), a)
+    rgba = rng.integers(0, 256, size=(4, 6, 4), dtype=np.uint8)
+    P.save_png(path, rgba)
+    np.testing.assert_array_equal(P.load_image8(path), rgba[:, :, :3])
+    with pytest.raises(ValueError):
+        P.save_png(path, rgba.astype(np.float32))
+    with pytest.raises(P.native.PtamdError):
+        P.save_png(str(tmp_path / "no_such_dir" / "x.png"), rgba)
+
+
 def _fake_images():
     """A tiny image set served through the provider callback: name -> float32[h, w, c]."""
     rng = np.random.default_rng(1)

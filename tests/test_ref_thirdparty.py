@@ -18,6 +18,8 @@ import hashlib
 import io
 import json
 import os
+import struct
+import zlib
 
 import numpy as np
 import pytest
@@ -266,6 +268,161 @@ def test_reference_libm_float_conversion_table(P, tmp_path):
     np.testing.assert_array_equal(m8, a8)
     np.testing.assert_array_equal(mf.view(np.uint32), af.view(np.uint32))
     assert len(np.unique(a8)) > 200
+
+
+# ------------------------------------------------------------------ PNG
+
+def _chunk(t, d):
+    return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+
+def _pack_rows(samples, depth):
+    rows = []
+    for s in samples:
+        if depth == 8:
+            rows.append(bytes(s.astype(np.uint8)))
+        elif depth == 16:
+            rows.append(s.astype(">u2").tobytes())
+        else:
+            per = 8 // depth
+            s2 = np.concatenate([s, np.zeros((-len(s)) % per, s.dtype)]).reshape(-1, per)
+            v = np.zeros(len(s2), np.int64)
+            for k in range(per):
+                v = (v << depth) | s2[:, k]
+            rows.append(bytes(v.astype(np.uint8)))
+    return rows
+
+
+def _filter_rows(rows, bpp, rng):
+    """Applies a random PNG filter type (0..4) to every row."""
+    out, prev = bytearray(), None
+    for r in rows:
+        ft = int(rng.integers(0, 5))
+        cur = np.frombuffer(r, np.uint8).astype(np.int64)
+        zero = np.zeros(len(cur), np.int64)
+        shift = lambda v: np.concatenate([np.zeros(bpp, np.int64), v[:-bpp]]) if len(v) > bpp else zero
+        a, b = shift(cur), (prev if prev is not None else zero)
+        c = shift(b)
+        if ft == 0: f = cur
+        elif ft == 1: f = cur - a
+        elif ft == 2: f = cur - b
+        elif ft == 3: f = cur - ((a + b) >> 1)
+        else:
+            p = a + b - c
+            pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+            f = cur - np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+        out.append(ft)
+        out += bytes((f & 255).astype(np.uint8))
+        prev = cur
+    return bytes(out)
+
+
+def make_png(rng, w, h, colour, depth, interlace, trns):
+    """A PNG of the given colour type / bit depth / interlace mode with random pixels, random filter per row, optional
+    tRNS (palette alpha, or a colour key that really occurs), IDAT split in two, ancillary chunks sprinkled in."""
+    n = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
+    pal = None
+    if colour == 3:
+        pal = rng.integers(0, 256, size=(int(rng.integers(1, min(256, 1 << depth) + 1)), 3)).astype(np.uint8)
+        img = rng.integers(0, len(pal), size=(h, w, 1))
+    else:
+        img = rng.integers(0, 1 << depth, size=(h, w, n))
+        if rng.random() < 0.5:
+            img[: h // 2 + 1] = img[0, 0]
+    bpp = 1 if depth < 8 else n * depth // 8
+    if not interlace:
+        data = _filter_rows(_pack_rows(img.reshape(h, w * n), depth), bpp, rng)
+    else:
+        data = b""
+        for x0, y0, dx, dy in zip((0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)):
+            sub = img[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                data += _filter_rows(_pack_rows(sub.reshape(sub.shape[0], -1), depth), bpp, rng)
+    out = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, interlace))
+    if rng.random() < 0.3:
+        out += _chunk(b"gAMA", struct.pack(">I", 45455))
+    if pal is not None:
+        out += _chunk(b"PLTE", pal.tobytes())
+        if trns:
+            out += _chunk(b"tRNS", bytes(rng.integers(0, 256, size=int(rng.integers(1, len(pal) + 1))).astype(np.uint8)))
+    elif trns and colour in (0, 2):
+        out += _chunk(b"tRNS", b"".join(struct.pack(">H", int(v)) for v in img[0, 0]))
+    z = zlib.compress(data, int(rng.choice([0, 1, 6, 9])))
+    cut = int(rng.integers(1, len(z))) if len(z) > 1 and rng.random() < 0.5 else len(z)
+    out += _chunk(b"IDAT", z[:cut])
+    if cut < len(z):
+        out += _chunk(b"IDAT", z[cut:])
+    if rng.random() < 0.3:
+        out += _chunk(b"tEXt", b"k\0v")
+    return out + _chunk(b"IEND", b"")
+
+
+PNG_KINDS = [(0, d) for d in (1, 2, 4, 8, 16)] + [(2, 8), (2, 16)] + [(3, d) for d in (1, 2, 4, 8)] + [(4, 8), (4, 16), (6, 8), (6, 16)]
+
+
+def png_cases(reps=3, seed=0):
+    rng = np.random.default_rng(seed)
+    for rep in range(reps):
+        for colour, depth in PNG_KINDS:
+            for interlace in (0, 1):
+                for trns in (False, True):
+                    w, h = (1, 1) if rep == 0 else (int(v) for v in rng.integers(1, 40, size=2))
+                    yield "c%dd%di%dt%d_%dx%d" % (colour, depth, interlace, trns, w, h), make_png(rng, w, h, colour, depth, interlace, trns)
+
+
+@live
+def test_png_decoder_matches_stb(P, tmp_path):
+    path = str(tmp_path / "t.png")
+    n = 0
+    for name, data in png_cases():
+        with open(path, "wb") as f:
+            f.write(data)
+        ref8 = R.stbi_load(path)
+        assert ref8 is not None, name
+        np.testing.assert_array_equal(P.load_image8(path), ref8, err_msg=name)
+        if n % 7 == 0:          # float rule incl. the linear alpha channel of 2- and 4-channel images
+            np.testing.assert_array_equal(P.load_image(path).view(np.uint32), R.stbi_loadf(path).view(np.uint32), err_msg=name)
+        n += 1
+    assert n == 3 * len(PNG_KINDS) * 4
+    from PIL import Image                                   # and an ordinary encoder's output
+    rng = np.random.default_rng(4)
+    for mode, c in (("L", 1), ("LA", 2), ("RGB", 3), ("RGBA", 4), ("P", 1)):
+        arr = rng.integers(0, 256, size=(37, 53, c), dtype=np.uint8)
+        Image.frombytes(mode, (53, 37), arr.tobytes()).save(path, "PNG", optimize=bool(c & 1))
+        np.testing.assert_array_equal(P.load_image8(path), R.stbi_load(path), err_msg=mode)
+
+
+def test_fixture_png_digest(P, fixture, tmp_path):
+    path = str(tmp_path / "t.png")
+    h = hashlib.sha256()
+    for name, data in png_cases(reps=2, seed=9):
+        with open(path, "wb") as f:
+            f.write(data)
+        img = P.load_image8(path)
+        h.update(np.array(img.shape, np.int32).tobytes() + img.tobytes())
+    assert h.hexdigest() == fixture["png_sha256"]
+
+
+def test_png_decoder_survives_corrupt_input(P, tmp_path):
+    rng = np.random.default_rng(8)
+    path = str(tmp_path / "c.png")
+    ok = errors = 0
+    for name, data in png_cases(reps=2, seed=5):
+        d = bytearray(data)
+        k = int(rng.integers(0, 3))
+        if k == 0:
+            d = d[: int(rng.integers(8, len(d)))]
+        else:
+            for _ in range(int(rng.integers(1, 6))):
+                d[int(rng.integers(8, len(d)))] = int(rng.integers(0, 256))
+        with open(path, "wb") as f:
+            f.write(d)
+        try:
+            assert P.load_image8(path).size > 0
+            ok += 1
+        except P.native.PtamdError:
+            errors += 1
+    assert ok + errors == 2 * len(PNG_KINDS) * 4 and errors > 20
 
 
 # ------------------------------------------------------------------ stbir_resize_float
