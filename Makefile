@@ -4,7 +4,9 @@ PKG      := cuda-pathtracer_amd
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: the kernel must execute the reference's IEEE op sequence
-HIPFLAGS := $(EXTRA_HIPFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(PKG)/host -I$(PKG)/csrc \
+# -fno-slp-vectorize -fno-vectorize: packed f32 VALU ops issue at half rate on gfx950 and the packing costs v_mov
+#   shuffles and spills; scalar code is 6.8 % faster (scripts/gpu_flags.sh)
+HIPFLAGS := $(EXTRA_HIPFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -Iinclude -I$(PKG)/host -I$(PKG)/csrc \
             -Wall -Wextra -Wno-unused-parameter
 LIB      := $(PKG)/libptamd.so
 SRCS     := $(PKG)/csrc/pt_kernels.hip $(PKG)/csrc/ptamd_api.cpp $(PKG)/host/scene_loader.cpp $(PKG)/host/bvh_builder.cpp $(PKG)/host/image_decode.cpp $(PKG)/host/image_png.cpp $(PKG)/host/image_resize.cpp

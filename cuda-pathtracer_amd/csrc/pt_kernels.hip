@@ -349,12 +349,19 @@ struct Nearest { float t, u, v; uint32_t idx; };
 #define PT_LIGHT 0x80000000u
 
 // The light loop of intersect() (intersection.cuh:199-212) applied to the face search's result.
+// The light table is read-only for the whole launch and indexed wave-uniformly here: read it through the constant
+// address space so the loads become s_load_dwordx4 (scalar cache, SGPR results) instead of per-lane VMEM loads with a
+// vmcnt(0) stall per light.
+typedef const __attribute__((address_space(4))) float* ConstF;
+PT_DEV ConstF as_constant(const float4* q) { return (ConstF)(uintptr_t)q; }
+
 PT_DEV Nearest nearest_lights(const KParams& p, f3 o, f3 d, Nearest n)
 {
+  const ConstF lights = as_constant(p.lights);     // 8 floats per light: color.xyz, vec.xyz, emission, radius
   for (uint32_t l = 0; l < p.n_lights; ++l) {
-    const float4 la = p.lights[l * 2 + 0], lb = p.lights[l * 2 + 1];
+    const ConstF L = lights + l * 8u;
     float t;
-    if (intersect_sphere(o, d, mk3(la.w, lb.x, lb.y), lb.w, t) && t < n.t && t >= 0.0f) {
+    if (intersect_sphere(o, d, mk3(L[3], L[4], L[5]), L[7], t) && t < n.t && t >= 0.0f) {
       n.t = t;
       n.idx = PT_LIGHT | l;
     }
