@@ -203,27 +203,28 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
 // compare needs 2 wait states (s_nop 1), exactly as hipcc pads it; SALU consumers are interlocked.
 PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count)
 {
-  uint32_t node = w.node, first, count;
-  const uint32_t lnk = lds_nodes + w.link_off * 4u; // byte address of this octant's link in node 0
-  unsigned long long save, m_a, m_b, m_int, m_leaf, parked;
+  // LDS nodes carry COMPACT links (stage_scene): dword 8 + o of a node = for ray octant o, the LDS byte address of the
+  // node to test next when this box is hit (low half: the nearer child) or not (high half: the miss link); 0xFFFF = end
+  // of the walk.  One v_cndmask with sub-dword selects picks the next address, so the loop needs no child / axis
+  // decode and no index -> address shift: 22 VALU per iteration instead of 33.
+  uint32_t addr = w.node == PT_END ? 0xFFFFu : lds_nodes + (w.node << 6);
+  uint32_t info;                                            // leaf word of the hit leaf this lane parks at, else 0
+  const uint32_t lnk = 32u + w.oct * 4u;                    // byte offset of this octant's link inside a node
+  unsigned long long save, m_a, m_b, m_leaf, parked;
   uint32_t npark;
   const uint32_t leaf_min = PT_LEAF_MIN; // the loop also ends when this many lanes hold a leaf
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
       "s_mov_b64 %[parked], 0\n\t"
-      "v_mov_b32 %[first], 0\n\t"
-      "v_mov_b32 %[count], 0\n\t"
-      "v_cmp_ne_u32 vcc, -1, %[node]\n\t"
+      "v_mov_b32 %[info], 0\n\t"
+      "v_cmp_ne_u32 vcc, 0xffff, %[addr]\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
       "s_cbranch_execz 2f\n\t"
       "1:\n\t"
-      "v_lshlrev_b32 v73, 6, %[node]\n\t"
-      "v_add_u32 v74, v73, %[lnk]\n\t"
-      "v_add_u32 v73, v73, %[base]\n\t"
-      "ds_read_b128 v[64:67], v73\n\t"                 // lo.xyz, leaf info
-      "ds_read_b128 v[68:71], v73 offset:16\n\t"       // hi.xyz, right child | axis
-      "ds_read_b32 v72, v74\n\t"                       // miss link of this ray's octant
-      "v_add_u32 v73, 1, %[node]\n\t"                  // left child = node + 1
+      "v_add_u32 v74, %[addr], %[lnk]\n\t"
+      "ds_read_b128 v[64:67], %[addr]\n\t"            // lo.xyz, leaf info
+      "ds_read_b128 v[68:71], %[addr] offset:16\n\t"  // hi.xyz
+      "ds_read_b32 v72, v74\n\t"                       // hit | miss << 16 for this ray's octant
       "s_waitcnt lgkmcnt(1)\n\t"
       "v_fma_f32 v64, v64, %[ix], %[nx]\n\t"
       "v_fma_f32 v68, v68, %[ix], %[nx]\n\t"
@@ -242,23 +243,15 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
       "v_cmp_le_f32 vcc, v74, v64\n\t"
       "v_cmp_le_f32 %[ma], 0, v64\n\t"
       "v_cmp_le_f32 %[mb], v74, %[best]\n\t"
-      "v_lshrrev_b32 v68, 24, v67\n\t"                 // count
-      "v_lshrrev_b32 v64, 30, v71\n\t"                 // split axis
-      "v_and_b32 v65, 0x3fffffff, v71\n\t"             // right child
-      "v_bfe_u32 v64, %[oct], v64, 1\n\t"              // ray goes negative along the axis?
+      "v_cmp_lt_u32 %[mleaf], %[leafbits], v67\n\t"    // count field non-zero: a leaf
       "s_and_b64 vcc, vcc, %[ma]\n\t"
-      "s_and_b64 vcc, vcc, %[mb]\n\t"                  // vcc = box hit
-      "v_cmp_eq_u32 %[mint], 0, v68\n\t"               // interior node
-      "v_cmp_ne_u32 %[ma], 0, v64\n\t"
-      "v_and_b32 v66, 0xffffff, v67\n\t"               // first triangle of a leaf
-      "s_andn2_b64 %[mleaf], vcc, %[mint]\n\t"         // hit & leaf
-      "s_and_b64 %[mint], vcc, %[mint]\n\t"            // hit & interior
-      "v_cndmask_b32 v73, v73, v65, %[ma]\n\t"         // near child (2+ wait states after the v_cmp above)
+      "s_and_b64 %[ma], vcc, %[mb]\n\t"                // box hit
+      "s_andn2_b64 vcc, %[ma], %[mleaf]\n\t"           // hit & interior: go down, else take the miss link
+      "s_and_b64 %[mleaf], %[ma], %[mleaf]\n\t"        // hit & leaf: park here
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_cndmask_b32 %[node], v72, v73, %[mint]\n\t"   // next = hit interior ? near child : miss link
-      "v_cndmask_b32 %[first], %[first], v66, %[mleaf]\n\t"
-      "v_cndmask_b32 %[count], %[count], v68, %[mleaf]\n\t"
-      "v_cmp_ne_u32 vcc, -1, %[node]\n\t"
+      "v_cndmask_b32_sdwa %[addr], v72, v72, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+      "v_cndmask_b32 %[info], %[info], v67, %[mleaf]\n\t"
+      "v_cmp_ne_u32 vcc, 0xffff, %[addr]\n\t"
       "s_andn2_b64 vcc, vcc, %[mleaf]\n\t"             // keep walking: not at a hit leaf and not off the tree
       "s_or_b64 %[parked], %[parked], %[mleaf]\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
@@ -268,15 +261,14 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
       "s_cbranch_scc1 1b\n\t"
       "2:\n\t"
       "s_mov_b64 exec, %[save]\n\t"
-      : [node] "+v"(node), [first] "=&v"(first), [count] "=&v"(count), [save] "=&s"(save), [ma] "=&s"(m_a),
-        [mb] "=&s"(m_b), [mint] "=&s"(m_int), [mleaf] "=&s"(m_leaf), [parked] "=&s"(parked), [npark] "=&s"(npark)
-      : [lnk] "v"(lnk), [base] "v"(lds_nodes), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
-        [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t), [oct] "v"(w.oct),
-        [leafmin] "s"(leaf_min)
-      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "vcc", "scc", "memory");
-  leaf_first = first;
-  leaf_count = count;
-  w.node = node;
+      : [addr] "+v"(addr), [info] "=&v"(info), [save] "=&s"(save), [ma] "=&s"(m_a), [mb] "=&s"(m_b),
+        [mleaf] "=&s"(m_leaf), [parked] "=&s"(parked), [npark] "=&s"(npark)
+      : [lnk] "v"(lnk), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
+        [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t), [leafmin] "s"(leaf_min), [leafbits] "s"(0xFFFFFFu)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v74", "vcc", "scc", "memory");
+  leaf_first = info & 0xFFFFFFu;
+  leaf_count = info >> 24;
+  w.node = addr == 0xFFFFu ? PT_END : (addr - lds_nodes) >> 6;
 }
 
 template <bool STATS>
@@ -726,7 +718,11 @@ PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t sampl
   }
 }
 
-template <int KIND, bool LDS_RESIDENT>
+// COMPACT (the asm box loop's layout): the node's eight per-octant miss links (dwords 8..15, node indices) are replaced
+// by eight words "hit address | miss address << 16" (LDS byte addresses, 0xFFFF = end): hit = the child a ray of that
+// octant visits first (left = node + 1, or the right child when the ray runs against the split axis), miss = the old
+// link.  A workgroup's LDS is at most 64 KB, so every node address fits 16 bits and 0xFFFF is never one.
+template <int KIND, bool LDS_RESIDENT, bool COMPACT = false>
 PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes, const float4*& s_tris)
 {
   if (LDS_RESIDENT) {
@@ -735,7 +731,29 @@ PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes,
       s_nodes = nullptr;
       s_tris = s_mem;
     } else {
-      stage_to_lds(s_mem, p.nodes, p.n_nodes * 4);
+      if (COMPACT) {
+        const uint32_t base = (uint32_t)(uintptr_t)s_mem;
+        for (uint32_t i = threadIdx.x; i < p.n_nodes; i += blockDim.x) {
+          const float4 q0 = p.nodes[i * 4 + 0], q1 = p.nodes[i * 4 + 1];
+          const uint4 m0 = *reinterpret_cast<const uint4*>(p.nodes + i * 4 + 2), m1 = *reinterpret_cast<const uint4*>(p.nodes + i * 4 + 3);
+          const uint32_t miss[8] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w };
+          const uint32_t child = f_as_u(q1.w), right = child & 0x3FFFFFFFu, axis = child >> 30;
+          const bool leaf = (f_as_u(q0.w) >> 24) != 0u;
+          uint32_t word[8];
+          for (uint32_t o = 0; o < 8; ++o) {
+            const uint32_t down = ((o >> axis) & 1u) ? right : i + 1u;
+            const uint32_t hit = leaf ? miss[o] : down;
+            const uint32_t ha = hit == PT_END ? 0xFFFFu : base + hit * 64u, ma = miss[o] == PT_END ? 0xFFFFu : base + miss[o] * 64u;
+            word[o] = ha | (ma << 16);
+          }
+          s_mem[i * 4 + 0] = q0;
+          s_mem[i * 4 + 1] = q1;
+          s_mem[i * 4 + 2] = make_float4(u_as_f(word[0]), u_as_f(word[1]), u_as_f(word[2]), u_as_f(word[3]));
+          s_mem[i * 4 + 3] = make_float4(u_as_f(word[4]), u_as_f(word[5]), u_as_f(word[6]), u_as_f(word[7]));
+        }
+      } else {
+        stage_to_lds(s_mem, p.nodes, p.n_nodes * 4);
+      }
       stage_to_lds(s_mem + p.n_nodes * 4, p.tris_bvh, p.n_bvh_tris * 3);
       s_nodes = s_mem;
       s_tris = s_mem + p.n_nodes * 4;
@@ -757,7 +775,7 @@ __global__ void __launch_bounds__(BLOCK, PT_TILE_WAVES_PER_EU) pt_megakernel(con
   extern __shared__ float4 s_mem[];
   const float4* s_nodes;
   const float4* s_tris;
-  stage_scene<KIND, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris);
+  stage_scene<KIND, LDS_RESIDENT, LDS_RESIDENT && !STATS && PT_ASM_WALK>(p, s_mem, s_nodes, s_tris);
 
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // BLOCK/64 waves as a 2 x (BLOCK/128) grid of 8x8 tiles: the block covers 16 x (BLOCK/16) pixels
@@ -788,7 +806,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
   extern __shared__ float4 s_mem[];
   const float4* s_nodes;
   const float4* s_tris;
-  stage_scene<KIND, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris);
+  stage_scene<KIND, LDS_RESIDENT, LDS_RESIDENT && !STATS && PT_ASM_WALK>(p, s_mem, s_nodes, s_tris);
 
   const uint32_t lane = threadIdx.x & 63u;
   Counters cnt = {};
@@ -893,7 +911,7 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
   extern __shared__ float4 s_mem[];
   const float4* s_nodes;
   const float4* s_tris;
-  stage_scene<2, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris);
+  stage_scene<2, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris);     // this kernel walks with the C++ loop: plain links
   // behind the staged scene: ray pool (2 float4 per slot), count table, pool head, ticket
   float4* pool = s_mem + (LDS_RESIDENT ? (p.n_nodes * 4u + p.n_bvh_tris * 3u) : 0u);
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(pool + PT_BW_THREADS * 2u);
@@ -1055,7 +1073,7 @@ __global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakern
   extern __shared__ float4 s_mem[];
   const float4* s_nodes;
   const float4* s_tris;
-  stage_scene<2, LDS_RESIDENT>(p, s_mem, s_nodes, s_tris); // zeroes nothing: control words are set below
+  stage_scene<2, LDS_RESIDENT, LDS_RESIDENT && !STATS && PT_ASM_WALK>(p, s_mem, s_nodes, s_tris); // zeroes nothing: control words are set below
   float4* rays = s_mem + (LDS_RESIDENT ? (p.n_nodes * 4u + p.n_bvh_tris * 3u) : 0u); // [NS][64][2]
   uint32_t* word = reinterpret_cast<uint32_t*>(rays + NS * 64u * 2u);               // [NS] n << 16 | claimed
   uint32_t* done = word + NS;                                                          // [NS]

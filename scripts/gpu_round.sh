@@ -21,16 +21,16 @@ find $OUT/prof_kernel -name "*kernel_stats*" | head -2
 # C++ host (examples/headless_render.cpp over raytrace.hpp) must produce the same picture as the Python host
 cd $R
 g++ -std=c++17 -O1 -Iinclude -Icuda-pathtracer_amd/host examples/headless_render.cpp -Lcuda-pathtracer_amd -lptamd -Wl,-rpath,$R/cuda-pathtracer_amd -o $OUT/headless_render && \
-  $OUT/headless_render assets/indoor.scene 320 180 8 $OUT/cpp.ppm && python - <<'PY'
+  $OUT/headless_render assets/crate_land.scene 320 180 8 $OUT/cpp.png && python - <<'PY'
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.getcwd())
 import cuda_pathtracer_amd as P
-hs = P.HostScene.load("assets/indoor.scene")
+hs = P.HostScene.load("assets/crate_land.scene")          # real textures, normal maps and the decoded cube cross on both hosts
 with P.Context(0) as ctx:
-    sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(P.cubemap_for_scene(hs))
+    sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(P.cubemap_for_scene(hs, asset_folder="assets"))
     fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), 320, 180)
     fr.render(spp=8, bounces=3); torch.cuda.synchronize()
     a = fr.surface.cpu().numpy()[:, :, :3]
-b = P.load_ppm("gpurun_out/cpp.ppm")
+b = P.load_image8("gpurun_out/cpp.png")
 print("C++ host == Python host:", bool(np.array_equal(a, b)))
 PY
