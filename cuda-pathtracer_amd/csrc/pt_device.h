@@ -186,6 +186,7 @@ PT_DEV float xorwow_uniform(Xorwow& st)
 
 struct TexDesc { int32_t w, h, nb_chan; uint32_t pad; uint64_t offset; };
 
+#define PT_HEAD_STRIDE 64u
 struct KParams {
   // scene (device pointers)
   const float4* nodes;      // 4 float4 per BVH node
@@ -218,6 +219,11 @@ struct KParams {
   unsigned long long* error_flag; // incremented when a bounded spin of the split kernel times out
   // persistent variant: 8x8 tiles over the row band, handed out by a ticket counter
   uint32_t* tile_counter;
+  // persistent kernel: eight ticket heads, PT_HEAD_STRIDE dwords apart (one per XCD; a single head saturates at ~88
+  // dequeues/us, MI355X_MICROARCH.md 'dequeue').  Head h hands out tickets n_static + 8 t + h; the first n_static
+  // tickets are taken by the waves without an atomic.
+  uint32_t* tile_heads;
+  uint32_t n_static;
   uint32_t tiles_x, n_tiles, tiles_per_ticket;
   uint32_t refill_min; // idle lanes that trigger a refill (1..64)
   // batched frames (persistent variant): `sample_count` consecutive static frames in one launch.

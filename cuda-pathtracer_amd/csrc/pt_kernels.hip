@@ -825,6 +825,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
   uint32_t tile_x0 = 0, tile_y0 = 0, tile_k = 0, qpos = 64;
   uint32_t tile = 0, tile_end = 0; // tiles [tile, tile_end) of the current ticket remain
   uint32_t ticket = blockIdx.x * (PT_PERSISTENT_THREADS / 64u) + (threadIdx.x >> 6);
+  uint32_t head = blockIdx.x & 7u, dry = 0;   // workgroups are dealt round-robin to the 8 XCDs: blockIdx & 7 = this XCD's head
   bool have_ticket = true;         // `ticket` not yet expanded into tiles
   bool exhausted = false;
 
@@ -842,14 +843,22 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
         if (qpos >= 64u) {
           if (exhausted) break;
           if (tile >= tile_end) {
+            const uint32_t total = p.n_tiles * p.sample_count; // (tile, frame) pairs
             if (!have_ticket) {
-              uint32_t t = 0;
-              if (lane == 0) t = atomicAdd(p.tile_counter, 1u);
-              ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+              // pull from this workgroup's XCD head; a head that has run dry sends the wave on to the next one for good
+              for (;;) {
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(p.tile_heads + head * PT_HEAD_STRIDE, 1u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                ticket = p.n_static + t * 8u + head;
+                if ((unsigned long long)ticket * p.tiles_per_ticket < total) break;
+                head = (head + 1u) & 7u;
+                if (++dry == 8u) break;
+              }
+              if (dry == 8u) { exhausted = true; break; }
             }
             have_ticket = false;
             tile = ticket * p.tiles_per_ticket;
-            const uint32_t total = p.n_tiles * p.sample_count; // tiles of sample 0, then sample 1, ...
             if (tile >= total) { exhausted = true; break; }
             tile_end = tile + p.tiles_per_ticket;
             if (tile_end > total) tile_end = total;

@@ -56,6 +56,7 @@ struct ptamd_context {
   unsigned long long* d_stats = nullptr;
   // persistent variant: ring of tile ticket counters (one per in-flight launch) and grid sizing
   uint32_t* d_tickets = nullptr;
+  uint32_t* d_heads = nullptr;   // kTicketRing sets of 8 ticket heads, PT_HEAD_STRIDE dwords apart (persistent kernel)
   uint32_t ticket_next = 0;
   int n_cus = 0;
   int blocks_per_cu[2] = { -1, -1 }; // [lds_resident]
@@ -233,6 +234,11 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     uint32_t n_blocks = (uint32_t)ctx->n_cus * (uint32_t)bpc;
     p.sample_count = count;
     p.frame_nb0 = l->frame_nb;
+    // Mid-path lane refill pays once paths are long enough for dead lanes to dominate the box loop
+    // (measured, batched 1080p: 4 bounces 4.65 vs 4.46 Gsamples/s without/with, 5: 3.90 vs 4.13,
+    // 6: 3.44 vs 3.92, 8: 2.89 vs 3.71); below that, whole-wave refill keeps primary rays coherent.
+    p.refill_min = ctx->refill_min ? ctx->refill_min : (l->bounces >= 5 ? 16u : 64u);
+    const uint32_t tiles_per_ticket = ctx->tiles_per_ticket;
     if (count > 1) {
       // seeds of frames frame_nb+1.. are hashed on the device; the tonemap uses the last frame number
       p.frame_nb_f = (float)(int)(l->frame_nb + count - 1u);
@@ -246,17 +252,19 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       }
       p.samples_out = ctx->d_samples;
     }
-    const uint32_t n_tickets = (p.n_tiles * count + ctx->tiles_per_ticket - 1u) / ctx->tiles_per_ticket;
+    const uint32_t n_tickets = (p.n_tiles * count + tiles_per_ticket - 1u) / tiles_per_ticket;
     const uint32_t useful = (n_tickets + waves_per_block - 1u) / waves_per_block;
     if (n_blocks > useful) n_blocks = useful;
-    // Mid-path lane refill pays once paths are long enough for dead lanes to dominate the box loop
-    // (measured, batched 1080p: 4 bounces 4.65 vs 4.46 Gsamples/s without/with, 5: 3.90 vs 4.13,
-    // 6: 3.44 vs 3.92, 8: 2.89 vs 3.71); below that, whole-wave refill keeps primary rays coherent.
-    p.refill_min = ctx->refill_min ? ctx->refill_min : (l->bounces >= 5 ? 16u : 64u);
-    p.tiles_per_ticket = ctx->tiles_per_ticket;
+    p.tiles_per_ticket = tiles_per_ticket;
     // tickets 0..n_waves-1 are taken statically by the waves; the shared counter hands out the rest
-    p.tile_counter = ctx->d_tickets + (ctx->ticket_next++ % kTicketRing);
-    PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)(n_blocks * waves_per_block), 1, stream));
+    const uint32_t slot = ctx->ticket_next++ % kTicketRing;
+    p.tile_counter = ctx->d_tickets + slot;
+    p.n_static = n_blocks * waves_per_block;
+    PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)p.n_static, 1, stream));
+    if (!split) {
+      p.tile_heads = ctx->d_heads + (size_t)slot * 8u * PT_HEAD_STRIDE;
+      PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_heads), 0, 8u * PT_HEAD_STRIDE, stream));
+    }
     if (split) { p.tiles_per_ticket = 1; e = launch_megakernel_split(p, resident, lds, stats, n_blocks, stream); }
     else e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
     if (e == hipSuccess && count > 1) e = launch_resolve(p, stream);
@@ -306,6 +314,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), 16 * sizeof(unsigned long long)));
   PT_HIP(hipMemset(ctx->d_stats, 0, 16 * sizeof(unsigned long long)));
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), kTicketRing * sizeof(uint32_t)));
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_heads), (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
   hipDeviceProp_t prop;
   PT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   ctx->n_cus = prop.multiProcessorCount;
@@ -333,6 +342,7 @@ void ptamd_destroy(ptamd_context* ctx)
   for (auto& c : ctx->cubemaps) (void)hipFree(c.faces);
   (void)hipFree(ctx->d_stats);
   (void)hipFree(ctx->d_tickets);
+  (void)hipFree(ctx->d_heads);
   (void)hipFree(ctx->d_samples);
   delete ctx;
 }
