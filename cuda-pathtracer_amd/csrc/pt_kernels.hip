@@ -352,8 +352,15 @@ PT_DEV Nearest nearest_lights(const KParams& p, f3 o, f3 d, Nearest n)
   const ConstF lights = as_constant(p.lights);     // 8 floats per light: color.xyz, vec.xyz, emission, radius
   for (uint32_t l = 0; l < p.n_lights; ++l) {
     const ConstF L = lights + l * 8u;
+    // the discriminant of intersect_sphere, same operations: when it is negative for every lane of the wave (the usual
+    // case for a small light) the correctly-rounded square root and everything after it is skipped for the whole wave
+    const f3 c = mk3(L[3], L[4], L[5]);
+    const f3 op = c - o;
+    const float b = dot(op, d);
+    const float disc = b * b - dot(op, op) + L[7] * L[7];
+    if (__builtin_amdgcn_ballot_w64(!(disc < 0.0f)) == 0ull) continue;
     float t;
-    if (intersect_sphere(o, d, mk3(L[3], L[4], L[5]), L[7], t) && t < n.t && t >= 0.0f) {
+    if (intersect_sphere(o, d, c, L[7], t) && t < n.t && t >= 0.0f) {
       n.t = t;
       n.idx = PT_LIGHT | l;
     }
@@ -393,8 +400,9 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
     hit.normal = normalize(mk3(la.w, lb.x, lb.y) - (n.t * d)); // intersection.cuh:208: origin ignored
     return hit.dist < PT_MAX_DIST;
   }
-  const float4* sh = p.shade + (size_t)n.idx * 5;
-  const float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3], s4 = sh[4];
+  // one burst of seven independent 16-byte loads: geometry, material and both texture descriptors of the face
+  const float4* sh = p.shade + (size_t)n.idx * 7;
+  const float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3], s4 = sh[4], s5 = sh[5], s6 = sh[6];
   const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
   const float u = n.u, v = n.v;
   const float w = 1.0f - u - v;
@@ -406,15 +414,16 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
   const f3 tangent = mk3(s3.w, s4.x, s4.y);
   hit.normal = surface_normal;
   hit.light = -1;
-  const int4 m = p.materials[f_as_u(s4.z)];
-  hit.ior = u_as_f((uint32_t)m.z);
-  const TexDesc tex = p.textures[m.x];
+  hit.ior = s4.w;
+  TexDesc tex;
+  tex.w = (int32_t)f_as_u(s5.x); tex.h = (int32_t)f_as_u(s5.y); tex.nb_chan = (int32_t)f_as_u(s5.z); tex.pad = 0; tex.offset = f_as_u(s5.w);
   const float* texel = p.texels + tex.offset + texture_idx(tex, uvx, uvy);
   hit.diffuse_col = mk3(texel[0], texel[1], texel[2]);
   hit.specular_col = texel[3];
   if (STATS) cnt.mesh_hits++;
-  if (m.y >= 0) {
-    const TexDesc nt = p.textures[m.y];
+  if (f_as_u(s6.x) != 0u) {
+    TexDesc nt;
+    nt.w = (int32_t)f_as_u(s6.x); nt.h = (int32_t)f_as_u(s6.y); nt.nb_chan = (int32_t)f_as_u(s6.z); nt.pad = 0; nt.offset = f_as_u(s6.w);
     const float* nx = p.texels + nt.offset + texture_idx(nt, uvx, uvy);
     const f3 nn = normalize((mk3(nx[0], nx[1], nx[2]) * 2.0f) - 1.0f);
     const f3 binormal = normalize(cross(tangent, surface_normal));

@@ -73,6 +73,7 @@ namespace ptamd {
 namespace {
 
 constexpr size_t kLdsBudget = 64 * 1024;
+constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit)
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
 constexpr uint32_t kMaxLeaf = 4;
 constexpr uint32_t kTicketRing = 1024;
@@ -355,6 +356,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
     set_error("ptamd_upload_scene: null table with non-zero count");
     return PTAMD_ERR_ARG;
   }
+  if (sc->n_texel_floats >= (1ull << 32)) { set_error("ptamd_upload_scene: more than 2^32 texel floats"); return PTAMD_ERR_LIMIT; }
   uint64_t total = 0;
   for (uint32_t m = 0; m < sc->n_meshes; ++m) total += sc->mesh_sizes[m];
   if (total != sc->n_faces) { set_error("ptamd_upload_scene: mesh_sizes do not sum to n_faces"); return PTAMD_ERR_ARG; }
@@ -381,7 +383,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   if (rc != PTAMD_OK) return rc;
 
   // storage-order {v0,e1,e2,idx} records for the brute-force variant, and the shading records
-  std::vector<float> brute((size_t)sc->n_faces * 12, 0.0f), shade((size_t)sc->n_faces * 20, 0.0f);
+  std::vector<float> brute((size_t)sc->n_faces * 12, 0.0f), shade((size_t)sc->n_faces * kShadeFloats, 0.0f);
   for (uint32_t i = 0; i < sc->n_faces; ++i) {
     const ptamd_face& f = sc->faces[i];
     float* t = &brute[(size_t)i * 12];
@@ -389,11 +391,24 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
     t[3] = f.vertices[1].x - f.vertices[0].x; t[4] = f.vertices[1].y - f.vertices[0].y; t[5] = f.vertices[1].z - f.vertices[0].z;
     t[6] = f.vertices[2].x - f.vertices[0].x; t[7] = f.vertices[2].y - f.vertices[0].y; t[8] = f.vertices[2].z - f.vertices[0].z;
     std::memcpy(&t[9], &i, 4);
-    float* s = &shade[(size_t)i * 20];
+    // self-contained shading record (one parallel burst of loads per hit instead of the dependent
+    // face -> material -> texture descriptor -> texel chain of intersection.cuh:216-243): 28 floats =
+    // n0 n1 n2 | uv0 uv1 uv2 | tangent | material id | ior | diffuse+spec map {w,h,nb_chan,offset} | normal map {..} (w = 0: none)
+    float* s = &shade[(size_t)i * kShadeFloats];
     std::memcpy(s, f.normals, 36);
     std::memcpy(s + 9, f.texcoords, 24);
     std::memcpy(s + 15, &f.tangent, 12);
     std::memcpy(s + 18, &f.material_id, 4);
+    const ptamd_material& m = sc->materials[f.material_id];
+    std::memcpy(s + 19, &m.ior, 4);
+    const ptamd_texture_desc& dt = sc->textures[m.diffuse_spec_map];
+    const int32_t d4[4] = { dt.w, dt.h, dt.nb_chan, (int32_t)(uint32_t)dt.offset };
+    std::memcpy(s + 20, d4, 16);
+    if (m.normal_map >= 0) {
+      const ptamd_texture_desc& nt = sc->textures[m.normal_map];
+      const int32_t n4[4] = { nt.w, nt.h, nt.nb_chan, (int32_t)(uint32_t)nt.offset };
+      std::memcpy(s + 24, n4, 16);
+    }
   }
   std::vector<int32_t> mats((size_t)sc->n_materials * 4, 0);
   for (uint32_t i = 0; i < sc->n_materials; ++i) {
