@@ -5,7 +5,7 @@
 // brdf}.cuh, cutils_math.h) as IEEE binary32 operations in the reference's evaluation
 // order; the translation unit is built with -ffp-contract=off so nothing is fused unless
 // written as an explicit fma.  What differs from the reference is everything AROUND the
-// arithmetic: geometry comes from LDS-staged 48-byte {v0,e1,e2} records, the nearest hit is
+// arithmetic: geometry comes from LDS-staged 48-byte {e1,e2,v0} records, the nearest hit is
 // found by an ordered stackless BVH walk, camera constants are hoisted to the host, the
 // RNG/transcendentals are the build's defined functions (DESIGN.md "Defined arithmetic").
 #pragma once

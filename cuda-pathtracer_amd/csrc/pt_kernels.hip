@@ -6,7 +6,7 @@
 // Shape of the kernel (MI355X-first, not a translation of the 16x16-thread CUDA launch):
 //   * one wave64 owns an 8x8 pixel tile, four waves (a 16x16 tile) form a workgroup;
 //   * at workgroup start the whole traversal working set — 64-byte BVH nodes and 48-byte
-//     {v0,e1,e2} triangle records — is staged into LDS with 16-byte coalesced loads, so
+//     {e1,e2,v0} triangle records — is staged into LDS with 16-byte coalesced loads, so
 //     the hot loop never touches HBM/L2 (scenes that do not fit fall back to L2-resident
 //     global reads through the same code);
 //   * nearest hit = stackless, per-octant ORDERED threaded BVH walk ("while-while": all
@@ -68,14 +68,14 @@ namespace ptamd {
 
 struct Best { float t, u, v; uint32_t idx; };
 
-// intersection.cuh:102-135 on a {v0,e1,e2} record; identical operation order.
+// intersection.cuh:102-135 on a {e1,e2,v0} record; identical operation order.
 // Accept rule: reference `t < best && t > 0` in storage order == lexicographic (t, idx).
 template <bool ORDERED>
 PT_DEV void mt_test(float4 a, float4 b, float4 c, f3 o, f3 d, Best& best)
 {
-  const f3 v0 = mk3(a.x, a.y, a.z);
-  const f3 e1 = mk3(a.w, b.x, b.y);
-  const f3 e2 = mk3(b.z, b.w, c.x);
+  const f3 e1 = mk3(a.x, a.y, a.z);
+  const f3 e2 = mk3(a.w, b.x, b.y);
+  const f3 v0 = mk3(b.z, b.w, c.x);
   const f3 p_vec = cross(d, e2);
   const float det = dot(e1, p_vec);
   // intersection.cuh:110 compares in double: (double)det < 1e-7.  1e-7f is the float nearest to

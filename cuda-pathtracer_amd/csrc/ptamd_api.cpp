@@ -382,14 +382,14 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   int rc = build_bvh(sc->faces, sc->n_faces, kBoxMargin, kMaxLeaf, bvh);
   if (rc != PTAMD_OK) return rc;
 
-  // storage-order {v0,e1,e2,idx} records for the brute-force variant, and the shading records
+  // storage-order {e1,e2,v0,idx} records for the brute-force variant, and the shading records
   std::vector<float> brute((size_t)sc->n_faces * 12, 0.0f), shade((size_t)sc->n_faces * kShadeFloats, 0.0f);
   for (uint32_t i = 0; i < sc->n_faces; ++i) {
     const ptamd_face& f = sc->faces[i];
     float* t = &brute[(size_t)i * 12];
-    t[0] = f.vertices[0].x; t[1] = f.vertices[0].y; t[2] = f.vertices[0].z;
-    t[3] = f.vertices[1].x - f.vertices[0].x; t[4] = f.vertices[1].y - f.vertices[0].y; t[5] = f.vertices[1].z - f.vertices[0].z;
-    t[6] = f.vertices[2].x - f.vertices[0].x; t[7] = f.vertices[2].y - f.vertices[0].y; t[8] = f.vertices[2].z - f.vertices[0].z;
+    t[0] = f.vertices[1].x - f.vertices[0].x; t[1] = f.vertices[1].y - f.vertices[0].y; t[2] = f.vertices[1].z - f.vertices[0].z;
+    t[3] = f.vertices[2].x - f.vertices[0].x; t[4] = f.vertices[2].y - f.vertices[0].y; t[5] = f.vertices[2].z - f.vertices[0].z;
+    t[6] = f.vertices[0].x; t[7] = f.vertices[0].y; t[8] = f.vertices[0].z;
     std::memcpy(&t[9], &i, 4);
     // self-contained shading record (one parallel burst of loads per hit instead of the dependent
     // face -> material -> texture descriptor -> texel chain of intersection.cuh:216-243): 28 floats =

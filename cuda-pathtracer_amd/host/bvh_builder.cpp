@@ -369,14 +369,15 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
       for (uint32_t fi : ids) {
         const ptamd_face& f = faces[fi];
         float* t = &out.tris[(size_t)tri_cursor * 12];
-        // e1/e2 are the reference's v0v1/v0v2 (intersection.cuh:106-107): same subtraction
-        t[0] = f.vertices[0].x; t[1] = f.vertices[0].y; t[2] = f.vertices[0].z;
-        t[3] = f.vertices[1].x - f.vertices[0].x;
-        t[4] = f.vertices[1].y - f.vertices[0].y;
-        t[5] = f.vertices[1].z - f.vertices[0].z;
-        t[6] = f.vertices[2].x - f.vertices[0].x;
-        t[7] = f.vertices[2].y - f.vertices[0].y;
-        t[8] = f.vertices[2].z - f.vertices[0].z;
+        // e1/e2 are the reference's v0v1/v0v2 (intersection.cuh:106-107): same subtraction.  Record order e1, e2, v0,
+        // index: the determinant test needs only the first 24 bytes, v0 and the index come with the second read
+        t[0] = f.vertices[1].x - f.vertices[0].x;
+        t[1] = f.vertices[1].y - f.vertices[0].y;
+        t[2] = f.vertices[1].z - f.vertices[0].z;
+        t[3] = f.vertices[2].x - f.vertices[0].x;
+        t[4] = f.vertices[2].y - f.vertices[0].y;
+        t[5] = f.vertices[2].z - f.vertices[0].z;
+        t[6] = f.vertices[0].x; t[7] = f.vertices[0].y; t[8] = f.vertices[0].z;
         t[9] = u2f(fi);
         tri_cursor++;
       }
@@ -439,14 +440,14 @@ void bvh_trace_host(const Bvh& bvh, const ptamd_face* faces, const float dir[3],
       const float* t = &bvh.tris[(size_t)(first + k) * 12];
       if (tris_tested) ++*tris_tested;
       // intersection.cuh:102-135, same operation order
-      const float e1x = t[3], e1y = t[4], e1z = t[5], e2x = t[6], e2y = t[7], e2z = t[8];
+      const float e1x = t[0], e1y = t[1], e1z = t[2], e2x = t[3], e2y = t[4], e2z = t[5];
       const float px = dir[1] * e2z - dir[2] * e2y;
       const float py = dir[2] * e2x - dir[0] * e2z;
       const float pz = dir[0] * e2y - dir[1] * e2x;
       const float det = e1x * px + e1y * py + e1z * pz;
       if (det < 1e-7f) continue; // == (double)det < 0.0000001 (intersection.cuh:110), see mt_test
       const float inv_det = 1.0f / det;
-      const float tx = origin[0] - t[0], ty = origin[1] - t[1], tz = origin[2] - t[2];
+      const float tx = origin[0] - t[6], ty = origin[1] - t[7], tz = origin[2] - t[8];
       const float u = (tx * px + ty * py + tz * pz) * inv_det;
       if (u < 0 || u > 1) continue;
       const float qx = ty * e1z - tz * e1y;

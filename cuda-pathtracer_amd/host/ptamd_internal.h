@@ -51,15 +51,15 @@ const ImageProvider* builtin_image_provider();
 // Binary SAH BVH, laid out for a stackless, per-octant ORDERED threaded traversal:
 //   node record = 64 bytes = 4 x float4
 //     q0 = { lo.x, lo.y, lo.z, bits(first_tri | count << 24) }   (count == 0: interior)
-//     q1 = { hi.x, hi.y, hi.z, 0 }
-//     q2,q3 = links[8]: for ray octant o (bit a set <=> dir[a] < 0),
-//             links[o] = hit_link | miss_link << 16 (node indices, 0xFFFF = end)
-//   interior: hit_link = the child nearer along the split axis for that octant,
-//             miss_link = where to go when the box is missed / the subtree is done
-//   leaf:     hit_link == miss_link (after its triangles, continue at miss_link)
+//     q1 = { hi.x, hi.y, hi.z, bits(right_child | split_axis << 30) }   (left child = node + 1, DFS pre-order)
+//     q2,q3 = miss[8]: for ray octant o (bit a set <=> dir[a] < 0), the node to test next when this box is
+//             missed or its subtree is done (0xFFFFFFFF = end of the walk)
+//   A ray visits the child nearer along the split axis first (right child when it runs against the axis).
+//   The kernels' LDS copy re-encodes the links as 16-bit hit|miss address pairs (pt_kernels.hip: stage_scene).
 // Triangles are re-ordered leaf-major; record = 48 bytes = 3 x float4
-//     t0 = { v0.x, v0.y, v0.z, e1.x }  t1 = { e1.y, e1.z, e2.x, e2.y }
-//     t2 = { e2.z, bits(global face index), 0, 0 }      with e1 = v1 - v0, e2 = v2 - v0
+//     t0 = { e1.x, e1.y, e1.z, e2.x }  t1 = { e2.y, e2.z, v0.x, v0.y }
+//     t2 = { v0.z, bits(global face index), 0, 0 }      with e1 = v1 - v0, e2 = v2 - v0
+// (edges first: the determinant test of Moller-Trumbore needs only the first 24 bytes)
 struct Bvh {
   std::vector<float> nodes;      // 16 floats per node
   std::vector<float> tris;       // 12 floats per triangle, leaf-major
@@ -67,8 +67,6 @@ struct Bvh {
   uint32_t n_tris = 0;           // triangle records (>= faces when references were split)
 };
 
-constexpr uint32_t kBvhEnd = 0xFFFFu;
-constexpr uint32_t kBvhMaxNodes = 0xFFFEu;
 
 // margin: absolute inflation added to every box face (see DESIGN.md "Conservative boxes")
 int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t max_leaf, Bvh& out);
