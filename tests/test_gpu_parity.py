@@ -322,6 +322,23 @@ def test_crate_land_with_real_textures_and_cubemap(P, O, gpu_ctx):
         assert_same(acc, rgba, *ref, f"crate_land textured/{kernel}")
 
 
+def test_scene_with_huge_coordinates(P, O, gpu_ctx):
+    """Coordinates around 1e5 (the reference's MAX_DIST): box margins scale with the coordinate (1e-6 relative), the 16-bit
+    LDS link addresses do not depend on scene size — same pixels on every variant."""
+    rng = np.random.default_rng(33)
+    tris = random_soup(rng, 60, extent=1.2, size=0.9) * np.float32(1.0e5)
+    lights = [((0.0, 0.5e5, 1.0e5), (1.0, 0.9, 0.8), 4.0, 0.8e5)]
+    hs = make_scene(P, tris, lights=lights)
+    hs.camera["position"] *= np.float32(1.0e5)
+    hs.camera["focus_dist"] *= np.float32(1.0e5)
+    cube = synthetic_cubemap(rng, 2)
+    ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 48, 32, spp=2, bounces=4)
+    assert (ref[0] > 0).any()
+    for kernel in KERNELS:
+        acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 4, kid(P, kernel))
+        assert_same(acc, rgba, *ref, f"far scene/{kernel}")
+
+
 def test_stats_are_consistent(P, O, gpu_ctx, indoor):
     """Instrumented launch: ray/mesh-hit counts equal the oracle's, BVH tests far fewer triangles."""
     import torch
