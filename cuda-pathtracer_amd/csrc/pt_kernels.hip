@@ -240,12 +240,11 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
       "v_max_f32 v66, v66, v70\n\t"
       "v_max3_f32 v74, v74, v68, v69\n\t"              // tnear
       "v_min3_f32 v64, v64, v65, v66\n\t"              // tfar
-      "v_cmp_le_f32 vcc, v74, v64\n\t"
-      "v_cmp_le_f32 %[ma], 0, v64\n\t"
-      "v_cmp_le_f32 %[mb], v74, %[best]\n\t"
+      // hit <=> tnear <= tfar && 0 <= tfar && tnear <= best  <=>  max(tnear, 0) <= min(tfar, best)   (best >= 0)
+      "v_max_f32 v74, 0, v74\n\t"
+      "v_min_f32 v64, v64, %[best]\n\t"
       "v_cmp_lt_u32 %[mleaf], %[leafbits], v67\n\t"    // count field non-zero: a leaf
-      "s_and_b64 vcc, vcc, %[ma]\n\t"
-      "s_and_b64 %[ma], vcc, %[mb]\n\t"                // box hit
+      "v_cmp_le_f32 %[ma], v74, v64\n\t"               // box hit
       "s_andn2_b64 vcc, %[ma], %[mleaf]\n\t"           // hit & interior: go down, else take the miss link
       "s_and_b64 %[mleaf], %[ma], %[mleaf]\n\t"        // hit & leaf: park here
       "s_waitcnt lgkmcnt(0)\n\t"
@@ -253,12 +252,17 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
       "v_cndmask_b32 %[info], %[info], v67, %[mleaf]\n\t"
       "v_cmp_ne_u32 vcc, 0xffff, %[addr]\n\t"
       "s_andn2_b64 vcc, vcc, %[mleaf]\n\t"             // keep walking: not at a hit leaf and not off the tree
+#if PT_LEAF_MIN < 64
       "s_or_b64 %[parked], %[parked], %[mleaf]\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
       "s_cbranch_execz 2f\n\t"
       "s_bcnt1_i32_b64 %[npark], %[parked]\n\t"        // enough lanes parked at a leaf: end the box phase early
       "s_cmp_lt_u32 %[npark], %[leafmin]\n\t"
       "s_cbranch_scc1 1b\n\t"
+#else
+      "s_and_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execnz 1b\n\t"
+#endif
       "2:\n\t"
       "s_mov_b64 exec, %[save]\n\t"
       : [addr] "+v"(addr), [info] "=&v"(info), [save] "=&s"(save), [ma] "=&s"(m_a), [mb] "=&s"(m_b),
