@@ -3,6 +3,7 @@
 //   g++ -std=c++17 -Iinclude -Icuda-pathtracer_amd/host examples/headless_render.cpp
 //       -Lcuda-pathtracer_amd -lptamd -Wl,-rpath,$PWD/cuda-pathtracer_amd -o headless_render
 //   ./headless_render assets/crate_land.scene 960 540 64 out.png      (.png or .ppm)
+#include "interop.hpp"
 #include "raytrace.hpp"
 
 #include <cstdio>
@@ -55,17 +56,23 @@ int main(int argc, char** argv)
   }
   CHECK(ptamd_upload_cubemap(ctx, cube.data(), cube_size, &cubemap_id));
   CHECK(ptamd_host::setupFunctionTables(ctx));
-  void *surface = nullptr, *tfb = nullptr;
-  CHECK(ptamd_device_alloc(ctx, (size_t)w * h * 4, &surface));
+  // driver::Interop stand-in: two RGBA8 surfaces; blit() hands the finished frame to the presenter (here: keep the last one)
+  std::vector<unsigned char> px;
+  ptamd_host::Interop interop(ctx, w, h, [&](const uint8_t* p, unsigned iw, unsigned ih) { px.assign(p, p + (size_t)iw * ih * 4); });
+  void* tfb = nullptr;
   CHECK(ptamd_device_alloc(ctx, (size_t)w * h * 12, &tfb));
   CHECK(ptamd_device_memset(ctx, tfb, 0, (size_t)w * h * 12, nullptr)); // cudaCalloc, gpu_processor.cpp:255
   ptamd_host::Scenes scenes{ ctx };
   ptamd_host::Cubemaps cubemaps{ ctx };
-  for (int f = 0; f < frames; ++f) // main.cpp:172-206 without the window
-    CHECK(ptamd_host::raytrace(surface, scenes, scene_id, cubemaps, (int)cubemap_id, &cam, w, h, nullptr,
-                               static_cast<float*>(tfb), false, 0));
-  std::vector<unsigned char> px((size_t)w * h * 4);
-  CHECK(ptamd_device_to_host(ctx, px.data(), surface, px.size(), nullptr));
+  for (int f = 0; f < frames; ++f) { // main.cpp:172-206 without the window
+    // GPUProcessor::render(), gpu_processor.cpp:365-386
+    CHECK(interop.map(nullptr));
+    CHECK(ptamd_host::raytrace(interop.getArray(), scenes, scene_id, cubemaps, (int)cubemap_id, &cam, interop.width(),
+                               interop.height(), nullptr, static_cast<float*>(tfb), false, 0));
+    CHECK(interop.unmap(nullptr));
+    if (f + 1 == frames) CHECK(interop.blit(nullptr));   // main.cpp:198 blits every frame; one presentation is enough here
+    interop.swap();                                        // main.cpp:200
+  }
   std::vector<unsigned char> rgb((size_t)w * h * 3);      // the surface's alpha is 0 (raytrace.cu:232): write RGB
   for (size_t i = 0; i < (size_t)w * h; ++i) std::memcpy(&rgb[i * 3], &px[i * 4], 3);
   const size_t len = std::strlen(argv[5]);
@@ -78,7 +85,7 @@ int main(int argc, char** argv)
     std::fwrite(rgb.data(), 1, rgb.size(), out);
     std::fclose(out);
   }
-  ptamd_device_free(ctx, surface);
+  interop.clean();
   ptamd_device_free(ctx, tfb);
   ptamd_destroy(ctx);
   ptamd_host_scene_free(hs);

@@ -68,3 +68,21 @@ def test_product_never_touches_the_oracle():
                         if hits:
                             bad.append((f, hits[:2]))
     assert not bad, bad
+
+
+def test_cpp_host_example_compiles_and_fails_loudly_without_gpu(P, tmp_path):
+    """examples/headless_render.cpp (C++ host over raytrace.hpp + interop.hpp, the mirrors of raytrace.h and
+    driver/interop.h) builds against the C-ABI with a plain g++; run here, without a GPU, it must stop at ptamd_create
+    with an error message — never render through some other path."""
+    import subprocess
+    exe = str(tmp_path / "headless_render")
+    lib_dir = os.path.join(ROOT, "cuda-pathtracer_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(lib_dir, "host"), os.path.join(ROOT, "examples", "headless_render.cpp"),
+                           "-L" + lib_dir, "-lptamd", "-Wl,-rpath," + lib_dir, "-o", exe])
+    import torch
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([exe, os.path.join(ROOT, "assets", "indoor.scene"), "32", "32", "1", str(tmp_path / "o.png")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "ptamd_create" in r.stderr and not os.path.exists(str(tmp_path / "o.png"))
