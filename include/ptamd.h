@@ -176,7 +176,7 @@ void ptamd_destroy(ptamd_context* ctx);
 
 /* Deep-copies a flattened scene to the device and builds the traversal structures
  * (replaces scene.cpp:177-283,370-391 + gpu_processor.cpp:178-238).  Host arrays are
- * copied; the caller keeps ownership. */
+ * copied; the caller keeps ownership.  Capacity: fewer than 2^32 texel floats in total (PTAMD_ERR_LIMIT). */
 int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* scene, uint32_t* out_scene_id);
 /* faces: 6*size*size float4 in +x,-x,+y,-y,+z,-z order (gpu_processor.cpp:134-153). */
 int ptamd_upload_cubemap(ptamd_context* ctx, const float* faces, uint32_t size, uint32_t* out_cubemap_id);
