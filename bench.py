@@ -47,8 +47,11 @@ def parse_args():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate HIP streams, each with its own context and "
                          "buffers (double buffering, as the reference double-buffers its GL renderbuffers: "
-                         "driver/interop.cpp:107-111).  0 = auto: 1 on one GPU, 2 on several GPUs so that the "
-                         "RCCL all-gather of frame i overlaps the render of frame i+1")
+                         "driver/interop.cpp:107-111).  0 = auto: 1 on one GPU, 3 on several GPUs so that the "
+                         "RCCL all-gather of frame i overlaps the render of frames i+1, i+2; each launch is then sized to "
+                         "1/3 of the GPU (ptamd_launch.machine_share) so that the small per-GPU bands co-reside")
+    ap.add_argument("--no-share", dest="share", action="store_false",
+                    help="with several frames in flight, size every launch to the whole GPU instead of its 1/n share")
     ap.add_argument("--sequential", action="store_true", help="one launch per spp instead of one batched launch per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -156,7 +159,7 @@ def main():
     if args.aperture is not None:
         hs.camera["aperture"] = args.aperture
     cube = P.cubemap_for_scene(hs)
-    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world > 1 else 1)
+    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (3 if world > 1 else 1)
     dev = torch.device("cuda", local_rank)
     y0, y1 = P.row_bands(H, world)[rank]
     batched = (not args.sequential) and args.kernel in ("persistent", "split") and spp > 1
@@ -169,7 +172,8 @@ def main():
             self.ctx.setup_function_tables()
             self.sid = self.ctx.upload_scene(hs)
             self.cid = self.ctx.upload_cubemap(cube)
-            self.fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True)
+            self.fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True,
+                                      machine_share=n_slots if args.share else 0)
             self.bg = P.BandGather(H, W, world, rank, dev) if (world > 1 or force_gather) else None
             self.stream = torch.cuda.current_stream() if use_current_stream else torch.cuda.Stream(device=dev)
 

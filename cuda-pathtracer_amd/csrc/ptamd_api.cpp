@@ -144,6 +144,7 @@ int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
   if (l->frame_count > 4096) { set_error("ptamd_raytrace: frame_count out of range (<= 4096)"); return PTAMD_ERR_ARG; }
   if (l->frame_count > 1 && l->moved) { set_error("ptamd_raytrace: batched frames must be static (moved = 0)"); return PTAMD_ERR_ARG; }
   if (l->kernel > PTAMD_KERNEL_BVH_SPLIT) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
+  if (l->machine_share > 64) { set_error("ptamd_raytrace: machine_share out of range (<= 64)"); return PTAMD_ERR_ARG; }
   return PTAMD_OK;
 }
 
@@ -253,6 +254,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       }
       p.samples_out = ctx->d_samples;
     }
+    if (l->machine_share > 1u) n_blocks = n_blocks / l->machine_share > 0u ? n_blocks / l->machine_share : 1u;
     const uint32_t n_tickets = (p.n_tiles * count + tiles_per_ticket - 1u) / tiles_per_ticket;
     const uint32_t useful = (n_tickets + waves_per_block - 1u) / waves_per_block;
     if (n_blocks > useful) n_blocks = useful;

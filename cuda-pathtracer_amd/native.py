@@ -70,7 +70,7 @@ class Launch(C.Structure):
                 ("width", C.c_uint32), ("height", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
                 ("frame_nb", C.c_uint32), ("bounces", C.c_uint32), ("moved", C.c_int32), ("post_id", C.c_uint32),
                 ("kernel", C.c_uint32), ("band_local_buffers", C.c_uint32), ("frame_count", C.c_uint32),
-                ("_reserved", C.c_uint32)]
+                ("machine_share", C.c_uint32)]
 
 
 class TraceStats(C.Structure):

@@ -116,7 +116,7 @@ class Context:
                     width: int, height: int, frame_nb: int, bounces: int = REFERENCE_BOUNCES,
                     moved: bool = False, post_id: int = POST_NONE, stream=None,
                     rows: Optional[tuple] = None, kernel: int = N.KERNEL_AUTO,
-                    band_local_buffers: bool = False, frame_count: int = 1) -> N.Launch:
+                    band_local_buffers: bool = False, frame_count: int = 1, machine_share: int = 0) -> N.Launch:
         l = N.Launch()
         l.surface_rgba8 = _ptr(array)
         l.temporal_framebuffer = _ptr(temporal_framebuffer)
@@ -129,6 +129,7 @@ class Context:
         l.moved, l.post_id, l.kernel = (1 if moved else 0), post_id, kernel
         l.band_local_buffers = 1 if band_local_buffers else 0
         l.frame_count = frame_count
+        l.machine_share = machine_share
         return l
 
     def raytrace_ex(self, launch: N.Launch) -> None:
@@ -178,12 +179,13 @@ class FrameRenderer:
     296-300).  Buffers are torch tensors on the context's device."""
 
     def __init__(self, ctx: Context, scene_id: int, cubemap_id: int, cam: N.Camera, width: int, height: int,
-                 rows: Optional[tuple] = None, band_local: bool = False):
+                 rows: Optional[tuple] = None, band_local: bool = False, machine_share: int = 0):
         import torch
         self.ctx, self.scene_id, self.cubemap_id, self.cam = ctx, scene_id, cubemap_id, cam
         self.width, self.height = width, height
         self.rows = rows if rows is not None else (0, height)
         self.band_local = band_local
+        self.machine_share = machine_share   # > 1: this renderer shares the GPU with that many launches in flight
         n_rows = (self.rows[1] - self.rows[0]) if band_local else height
         dev = torch.device("cuda", ctx.device)
         self.surface = torch.zeros((n_rows, width, 4), dtype=torch.uint8, device=dev)
@@ -201,12 +203,12 @@ class FrameRenderer:
             l = self.ctx.make_launch(self.surface, self.accum, self.scene_id, self.cubemap_id, self.cam,
                                      self.width, self.height, frame_nb=first_frame, bounces=bounces, post_id=post_id,
                                      stream=stream, rows=self.rows, kernel=kernel,
-                                     band_local_buffers=self.band_local, frame_count=spp)
+                                     band_local_buffers=self.band_local, frame_count=spp, machine_share=self.machine_share)
             self.ctx.raytrace_ex(l)
             return
         for k in range(first_frame, first_frame + spp):
             l = self.ctx.make_launch(self.surface, self.accum, self.scene_id, self.cubemap_id, self.cam,
                                      self.width, self.height, frame_nb=k, bounces=bounces, post_id=post_id,
                                      stream=stream, rows=self.rows, kernel=kernel,
-                                     band_local_buffers=self.band_local)
+                                     band_local_buffers=self.band_local, machine_share=self.machine_share)
             self.ctx.raytrace_ex(l)

@@ -228,7 +228,9 @@ typedef struct {
   uint32_t frame_count;        /* 0 or 1: one frame.  N > 1 (static frames, persistent kernel only): frames
                                   frame_nb .. frame_nb+N-1 in ONE launch — same accumulator and final surface
                                   as N consecutive calls, bit for bit; intermediate surfaces are not produced */
-  uint32_t _reserved;
+  uint32_t machine_share;      /* persistent kernels: 0 or 1 = size the grid to the whole GPU; k > 1 = to 1/k of it, so that
+                                  k launches in flight (one per stream) co-reside instead of queueing behind each other —
+                                  what a multi-GPU host does with its small per-GPU bands (results do not depend on it) */
 } ptamd_launch;
 
 int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch);
