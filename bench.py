@@ -13,6 +13,12 @@ contiguous pixel-row bands (cuda_pathtracer_amd.tiles), each rank renders its ba
 global-coordinate seeds, and the finished RGBA8 bands are gathered with one RCCL all-gather
 per frame.  The frame is fixed, so scaling is "strong".
 
+On several GPUs three frames are in flight on separate HIP streams, each launch sized to a third of the GPU
+(ptamd_launch.machine_share), so that a frame's all-gather, ramp, tail and resolve pass overlap the bulk of the
+next ones; all K timed steps start and finish inside the timed region.  On one GPU the default is one frame in
+flight, which keeps "kernel time = step time" for the roofline (pipelining is worth +2..5 % there:
+--frames-in-flight 2).
+
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and, at N = 1,
 `cpu_baseline` (the CPU oracle timed on the host cores — a reported baseline, not the target).
 """
@@ -26,6 +32,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto 4 hardware queues by default; two frames-in-flight streams sharing a queue would serialise
+# (measured: -30 %).  Frames + the RCCL stream + torch's own streams need more than 4: ask for 8 before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 4, 4
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
@@ -47,9 +56,9 @@ def parse_args():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate HIP streams, each with its own context and "
                          "buffers (double buffering, as the reference double-buffers its GL renderbuffers: "
-                         "driver/interop.cpp:107-111).  0 = auto: 1 on one GPU, 3 on several GPUs so that the "
-                         "RCCL all-gather of frame i overlaps the render of frames i+1, i+2; each launch is then sized to "
-                         "1/3 of the GPU (ptamd_launch.machine_share) so that the small per-GPU bands co-reside")
+                         "driver/interop.cpp:107-111).  0 = auto: 1 on one GPU, 3 on several GPUs (the RCCL "
+                         "all-gather of frame i overlaps the render of frames i+1, i+2); each launch is sized to 1/n of "
+                         "the GPU (ptamd_launch.machine_share) so that the launches co-reside")
     ap.add_argument("--no-share", dest="share", action="store_false",
                     help="with several frames in flight, size every launch to the whole GPU instead of its 1/n share")
     ap.add_argument("--sequential", action="store_true", help="one launch per spp instead of one batched launch per frame")
@@ -275,6 +284,9 @@ def main():
                        "parallelism": f"rows/{world}" + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         # launches in flight co-reside (each on 1/n of the GPU): a launch lasts ~n times its share of the
+                         # step; `achieved` is per launch as defined, the chip-wide rate is n times that
+                         "concurrent_launches": n_slots, "achieved_all_launches": round(achieved * n_slots, 2),
                          "kernel": {"persistent": "pt_megakernel_persistent", "blockwise": "pt_megakernel_blockwise", "split": "pt_megakernel_split"}.get(args.kernel, "pt_megakernel"), "kernel_ms_per_launch": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes_launch),
                          "samples_per_launch": int(stats["samples"] / spp * frames_per_launch),
