@@ -263,7 +263,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     const uint32_t slot = ctx->ticket_next++ % kTicketRing;
     p.tile_counter = ctx->d_tickets + slot;
     p.n_static = n_blocks * waves_per_block;
-    PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)p.n_static, 1, stream));
+    if (split) PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)p.n_static, 1, stream));
     if (!split) {
       p.tile_heads = ctx->d_heads + (size_t)slot * 8u * PT_HEAD_STRIDE;
       PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_heads), 0, 8u * PT_HEAD_STRIDE, stream));

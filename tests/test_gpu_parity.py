@@ -322,6 +322,40 @@ def test_crate_land_with_real_textures_and_cubemap(P, O, gpu_ctx):
         assert_same(acc, rgba, *ref, f"crate_land textured/{kernel}")
 
 
+def test_random_scenes_fuzz(P, O, gpu_ctx):
+    """Seeded random scenes (triangle soups with textures, normal maps, refractive materials, 0-4 lights, random camera
+    lens, ragged frame sizes, 1-7 bounces, every post-process) through the default kernel and the tile kernel."""
+    for seed in range(14):
+        rng = np.random.default_rng(1000 + seed)
+        n = int(rng.integers(20, 400))
+        tris = random_soup(rng, n, extent=float(rng.uniform(0.8, 3.0)), size=float(rng.uniform(0.2, 1.2)))
+        uvs = rng.uniform(-1.0, 2.0, size=(n, 3, 2)).astype(np.float32)
+        textures = [rng.uniform(0.05, 0.95, size=(int(rng.integers(1, 9)), int(rng.integers(1, 9)), 4)).astype(np.float32),
+                    rng.uniform(0.0, 1.0, size=(int(rng.integers(1, 6)), int(rng.integers(1, 6)), 3)).astype(np.float32),
+                    np.float32([[[0.9, 0.8, 0.7, float(rng.uniform(0, 1))]]])]
+        materials = [(0, 1, 1.0), (0, -1, 1.0), (2, -1, float(rng.uniform(1.1, 1.8))), (2, 1, 1.0)]
+        lights = [(tuple(rng.uniform(-2, 2, 3)), tuple(rng.uniform(0.2, 1, 3)), float(rng.uniform(1, 6)), float(rng.uniform(0.1, 0.8)))
+                  for _ in range(int(rng.integers(0, 5)))]
+        hs = make_scene(P, tris, uvs=uvs, material_ids=rng.integers(0, 4, size=n), materials=materials, textures=textures, lights=lights,
+                        mesh_sizes=None)
+        hs.camera["aperture"] = np.float32(rng.uniform(0.0, 0.2))
+        hs.camera["focus_dist"] = np.float32(rng.uniform(0.5, 4.0))
+        cube = synthetic_cubemap(rng, int(rng.choice([1, 2, 4])))
+        W, H = int(rng.integers(1, 70)), int(rng.integers(1, 50))
+        spp, B, post = int(rng.integers(1, 4)), int(rng.integers(1, 8)), int(rng.integers(0, 4))
+        ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), W, H, spp=spp, bounces=B, post_id=post)
+        for kernel in ("persistent", "bvh"):
+            acc, rgba = gpu_render(P, gpu_ctx, hs, cube, W, H, spp, B, kid(P, kernel), post_id=post)
+            assert_same(acc, rgba, *ref, f"fuzz seed {seed} {W}x{H} spp{spp} B{B} post{post}/{kernel}")
+        # the same frames as ONE batched launch on a third of the GPU (what a host with frames in flight issues)
+        import torch
+        sid, cid = gpu_ctx.upload_scene(hs), gpu_ctx.upload_cubemap(cube)
+        fr = P.FrameRenderer(gpu_ctx, sid, cid, hs.camera_struct(), W, H, machine_share=3)
+        fr.render(spp=spp, bounces=B, post_id=post, batched=True)
+        torch.cuda.synchronize()
+        assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref, f"fuzz seed {seed} batched, machine_share 3")
+
+
 def test_scene_with_huge_coordinates(P, O, gpu_ctx):
     """Coordinates around 1e5 (the reference's MAX_DIST): box margins scale with the coordinate (1e-6 relative), the 16-bit
     LDS link addresses do not depend on scene size — same pixels on every variant."""
