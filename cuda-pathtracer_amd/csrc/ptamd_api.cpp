@@ -226,6 +226,10 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     p.tiles_x = (l->width + 7u) / 8u;
     p.n_tiles = p.tiles_x * ((rows + 7u) / 8u);
     if (p.n_tiles == 0) return PTAMD_OK;
+    if ((uint64_t)p.n_tiles * count >= (1ull << 31)) {   // (tile, frame) tickets are 32-bit
+      set_error("ptamd_raytrace: rows x width x frame_count too large for one launch (split the batch)");
+      return PTAMD_ERR_LIMIT;
+    }
     int& bpc = split ? ctx->sp_blocks_per_cu[resident ? 1 : 0] : ctx->blocks_per_cu[resident ? 1 : 0];
     if (bpc < 0) {
       e = split ? split_blocks_per_cu(resident, lds, &bpc) : persistent_blocks_per_cu(resident, lds, &bpc);
