@@ -117,6 +117,7 @@ PT_DEV void traverse_brute(const float4* tris, uint32_t n_faces, f3 o, f3 d, Bes
 struct Walk {
   f3 o, d, inv, noi; // ray, 1/d, -o/d
   uint32_t link_off; // dword offset of this ray's octant inside a node's miss-link table
+  uint32_t n_nodes;  // compact LDS layout: the link array starts 32 * n_nodes bytes after the box array
   uint32_t oct;
   uint32_t node;     // next node to test, PT_END when the walk is over
   Best best;
@@ -138,6 +139,7 @@ PT_DEV void walk_init(Walk& w, f3 o, f3 d, uint32_t n_nodes)
   w.inv = mk3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
   w.noi = mk3(-(o.x * w.inv.x), -(o.y * w.inv.y), -(o.z * w.inv.z));
   w.link_off = 8u + w.oct;
+  w.n_nodes = n_nodes;
   w.node = n_nodes ? 0u : PT_END;
   w.best.t = PT_MAX_DIST; w.best.u = 0.f; w.best.v = 0.f; w.best.idx = PT_END;
   w.alive = 64u; w.idle_unstarted = w.idle_finished = w.idle_parked = 0u;
@@ -203,76 +205,72 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
 // compare needs 2 wait states (s_nop 1), exactly as hipcc pads it; SALU consumers are interlocked.
 PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count)
 {
-  // LDS nodes carry COMPACT links (stage_scene): dword 8 + o of a node = for ray octant o, the LDS byte address of the
-  // node to test next when this box is hit (low half: the nearer child) or not (high half: the miss link); 0xFFFF = end
-  // of the walk.  One v_cndmask with sub-dword selects picks the next address, so the loop needs no child / axis
-  // decode and no index -> address shift: 22 VALU per iteration instead of 33.
-  uint32_t addr = w.node == PT_END ? 0xFFFFu : lds_nodes + (w.node << 6);
-  uint32_t info;                                            // leaf word of the hit leaf this lane parks at, else 0
-  const uint32_t lnk = 32u + w.oct * 4u;                    // byte offset of this octant's link inside a node
-  unsigned long long save, m_a, m_b, m_leaf, parked;
-  uint32_t npark;
-  const uint32_t leaf_min = PT_LEAF_MIN; // the loop also ends when this many lanes hold a leaf
+  // COMPACT LDS nodes (stage_scene), two arrays of 32-byte records, N nodes each:
+  //   boxes[n] at lds_nodes + 32 n:          dwords 0..3 lo.xyz hi.x | 4..5 hi.yz | 6 leaf word
+  //   links[n] at lds_nodes + 32 N + 32 n:   one word per ray octant
+  // links[n][o] = hit code | miss code << 16, 16 bits each:
+  //   < 0x8000  LDS byte address of the box to test next          0xFFFF  end of the walk
+  //   0x8000 | (addr >> 1)  "park at the leaf whose box is at addr" (only ever a hit code, of the leaf itself)
+  // so one v_cndmask with sub-dword selects yields the next state and one unsigned compare says whether to keep
+  // walking: 21 VALU, 4 SALU and 8 LDS cycles per iteration (the plain layout took 33 / 20 / 10).  A lane that parks
+  // stops executing; its leaf word and miss link are fetched once, after the loop.
+  uint32_t state = w.node == PT_END ? 0xFFFFu : lds_nodes + (w.node << 5);
+  const uint32_t lnk = w.n_nodes * 32u + w.oct * 4u;        // from a node's box to its link word for this ray's octant
+  unsigned long long save;
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
-      "s_mov_b64 %[parked], 0\n\t"
-      "v_mov_b32 %[info], 0\n\t"
-      "v_cmp_ne_u32 vcc, 0xffff, %[addr]\n\t"
+      "v_cmp_gt_u32 vcc, 0x8000, %[st]\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
       "s_cbranch_execz 2f\n\t"
       "1:\n\t"
-      "v_add_u32 v74, %[addr], %[lnk]\n\t"
-      "ds_read_b128 v[64:67], %[addr]\n\t"            // lo.xyz, leaf info
-      "ds_read_b128 v[68:71], %[addr] offset:16\n\t"  // hi.xyz
+      "v_add_u32 v74, %[st], %[lnk]\n\t"
+      "ds_read_b128 v[64:67], %[st]\n\t"              // lo.xyz, hi.x
+      "ds_read_b64 v[68:69], %[st] offset:16\n\t"     // hi.yz
       "ds_read_b32 v72, v74\n\t"                       // hit | miss << 16 for this ray's octant
       "s_waitcnt lgkmcnt(1)\n\t"
       "v_fma_f32 v64, v64, %[ix], %[nx]\n\t"
-      "v_fma_f32 v68, v68, %[ix], %[nx]\n\t"
+      "v_fma_f32 v67, v67, %[ix], %[nx]\n\t"
       "v_fma_f32 v65, v65, %[iy], %[ny]\n\t"
-      "v_fma_f32 v69, v69, %[iy], %[ny]\n\t"
+      "v_fma_f32 v68, v68, %[iy], %[ny]\n\t"
       "v_fma_f32 v66, v66, %[iz], %[nz]\n\t"
-      "v_fma_f32 v70, v70, %[iz], %[nz]\n\t"
-      "v_min_f32 v74, v64, v68\n\t"
-      "v_max_f32 v64, v64, v68\n\t"
-      "v_min_f32 v68, v65, v69\n\t"
-      "v_max_f32 v65, v65, v69\n\t"
-      "v_min_f32 v69, v66, v70\n\t"
-      "v_max_f32 v66, v66, v70\n\t"
-      "v_max3_f32 v74, v74, v68, v69\n\t"              // tnear
+      "v_fma_f32 v69, v69, %[iz], %[nz]\n\t"
+      "v_min_f32 v74, v64, v67\n\t"
+      "v_max_f32 v64, v64, v67\n\t"
+      "v_min_f32 v67, v65, v68\n\t"
+      "v_max_f32 v65, v65, v68\n\t"
+      "v_min_f32 v68, v66, v69\n\t"
+      "v_max_f32 v66, v66, v69\n\t"
+      "v_max3_f32 v74, v74, v67, v68\n\t"              // tnear
       "v_min3_f32 v64, v64, v65, v66\n\t"              // tfar
       // hit <=> tnear <= tfar && 0 <= tfar && tnear <= best  <=>  max(tnear, 0) <= min(tfar, best)   (best >= 0)
       "v_max_f32 v74, 0, v74\n\t"
       "v_min_f32 v64, v64, %[best]\n\t"
-      "v_cmp_lt_u32 %[mleaf], %[leafbits], v67\n\t"    // count field non-zero: a leaf
-      "v_cmp_le_f32 %[ma], v74, v64\n\t"               // box hit
-      "s_andn2_b64 vcc, %[ma], %[mleaf]\n\t"           // hit & interior: go down, else take the miss link
-      "s_and_b64 %[mleaf], %[ma], %[mleaf]\n\t"        // hit & leaf: park here
+      "v_cmp_le_f32 vcc, v74, v64\n\t"                 // box hit
       "s_waitcnt lgkmcnt(0)\n\t"
-      "v_cndmask_b32_sdwa %[addr], v72, v72, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
-      "v_cndmask_b32 %[info], %[info], v67, %[mleaf]\n\t"
-      "v_cmp_ne_u32 vcc, 0xffff, %[addr]\n\t"
-      "s_andn2_b64 vcc, vcc, %[mleaf]\n\t"             // keep walking: not at a hit leaf and not off the tree
-#if PT_LEAF_MIN < 64
-      "s_or_b64 %[parked], %[parked], %[mleaf]\n\t"
-      "s_and_b64 exec, exec, vcc\n\t"
-      "s_cbranch_execz 2f\n\t"
-      "s_bcnt1_i32_b64 %[npark], %[parked]\n\t"        // enough lanes parked at a leaf: end the box phase early
-      "s_cmp_lt_u32 %[npark], %[leafmin]\n\t"
-      "s_cbranch_scc1 1b\n\t"
-#else
+      "s_nop 0\n\t"                                    // a VALU read of VCC needs 2 wait states after the VALU compare that wrote it
+      "v_cndmask_b32_sdwa %[st], v72, v72, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+      "v_cmp_gt_u32 vcc, 0x8000, %[st]\n\t"            // a node address: keep walking (else parked at a leaf, or done)
       "s_and_b64 exec, exec, vcc\n\t"
       "s_cbranch_execnz 1b\n\t"
-#endif
       "2:\n\t"
       "s_mov_b64 exec, %[save]\n\t"
-      : [addr] "+v"(addr), [info] "=&v"(info), [save] "=&s"(save), [ma] "=&s"(m_a), [mb] "=&s"(m_b),
-        [mleaf] "=&s"(m_leaf), [parked] "=&s"(parked), [npark] "=&s"(npark)
+      : [st] "+v"(state), [save] "=&s"(save)
       : [lnk] "v"(lnk), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
-        [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t), [leafmin] "s"(leaf_min), [leafbits] "s"(0xFFFFFFu)
-      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v74", "vcc", "scc", "memory");
-  leaf_first = info & 0xFFFFFFu;
-  leaf_count = info >> 24;
-  w.node = addr == 0xFFFFu ? PT_END : (addr - lds_nodes) >> 6;
+        [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v72", "v74", "vcc", "scc", "memory");
+  leaf_first = 0u;
+  leaf_count = 0u;
+  if (state == 0xFFFFu) {
+    w.node = PT_END;
+  } else {                                                   // parked: 0x8000 | (address of the leaf's node >> 1)
+    typedef const __attribute__((address_space(3))) uint32_t* LdsU32;
+    const uint32_t leaf_addr = (state & 0x7FFFu) << 1;
+    const uint32_t info = *(LdsU32)(uintptr_t)(leaf_addr + 24u);
+    const uint32_t miss = *(LdsU32)(uintptr_t)(leaf_addr + lnk) >> 16;
+    leaf_first = info & 0xFFFFFFu;
+    leaf_count = info >> 24;
+    w.node = miss == 0xFFFFu ? PT_END : (miss - lds_nodes) >> 5;
+  }
 }
 
 template <bool STATS>
@@ -731,10 +729,14 @@ PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t sampl
   }
 }
 
-// COMPACT (the asm box loop's layout): the node's eight per-octant miss links (dwords 8..15, node indices) are replaced
-// by eight words "hit address | miss address << 16" (LDS byte addresses, 0xFFFF = end): hit = the child a ray of that
-// octant visits first (left = node + 1, or the right child when the ray runs against the split axis), miss = the old
-// link.  A workgroup's LDS is at most 64 KB, so every node address fits 16 bits and 0xFFFF is never one.
+// COMPACT (the asm box loop's layout, see walk_to_leaf_lds): the 64-byte node is split into a 32-byte box record
+// (lo.xyz hi.x | hi.yz | leaf word) and a 32-byte link record in a second array; the eight per-octant miss links (node
+// indices) become eight words "hit code | miss code << 16": a code below 0x8000 is the LDS byte address of the next
+// box (hit: the child a ray of that octant visits first — left = node + 1, or the right child when the ray runs against
+// the split axis; miss: the old link), 0xFFFF ends the walk, and a leaf's hit code is 0x8000 | (its own address >> 1).
+// Box addresses must stay below 0x8000: 32 bytes per node, nodes first in LDS, so up to ~900 nodes — more than an
+// LDS-resident scene can have (64 bytes of links + boxes and >= 48 bytes of triangles per node pair in 64 KB); the
+// host checks it (ptamd_api.cpp: kCompactMaxNodes) and walks bigger trees from global memory.
 template <int KIND, bool LDS_RESIDENT, bool COMPACT = false>
 PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes, const float4*& s_tris)
 {
@@ -752,17 +754,20 @@ PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes,
           const uint32_t miss[8] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w };
           const uint32_t child = f_as_u(q1.w), right = child & 0x3FFFFFFFu, axis = child >> 30;
           const bool leaf = (f_as_u(q0.w) >> 24) != 0u;
+          const uint32_t self = base + i * 32u;
           uint32_t word[8];
           for (uint32_t o = 0; o < 8; ++o) {
             const uint32_t down = ((o >> axis) & 1u) ? right : i + 1u;
-            const uint32_t hit = leaf ? miss[o] : down;
-            const uint32_t ha = hit == PT_END ? 0xFFFFu : base + hit * 64u, ma = miss[o] == PT_END ? 0xFFFFu : base + miss[o] * 64u;
+            // hit code: a leaf parks at itself; an interior node sends the ray to its nearer child
+            const uint32_t ha = leaf ? (0x8000u | (self >> 1)) : base + down * 32u;
+            const uint32_t ma = miss[o] == PT_END ? 0xFFFFu : base + miss[o] * 32u;
             word[o] = ha | (ma << 16);
           }
-          s_mem[i * 4 + 0] = q0;
-          s_mem[i * 4 + 1] = q1;
-          s_mem[i * 4 + 2] = make_float4(u_as_f(word[0]), u_as_f(word[1]), u_as_f(word[2]), u_as_f(word[3]));
-          s_mem[i * 4 + 3] = make_float4(u_as_f(word[4]), u_as_f(word[5]), u_as_f(word[6]), u_as_f(word[7]));
+          float4* links = s_mem + p.n_nodes * 2u;
+          s_mem[i * 2 + 0] = make_float4(q0.x, q0.y, q0.z, q1.x);
+          s_mem[i * 2 + 1] = make_float4(q1.y, q1.z, q0.w, 0.0f);
+          links[i * 2 + 0] = make_float4(u_as_f(word[0]), u_as_f(word[1]), u_as_f(word[2]), u_as_f(word[3]));
+          links[i * 2 + 1] = make_float4(u_as_f(word[4]), u_as_f(word[5]), u_as_f(word[6]), u_as_f(word[7]));
         }
       } else {
         stage_to_lds(s_mem, p.nodes, p.n_nodes * 4);

@@ -73,6 +73,7 @@ namespace ptamd {
 namespace {
 
 constexpr size_t kLdsBudget = 64 * 1024;
+constexpr uint32_t kCompactMaxNodes = 896;   // 896 * 32 B = 28 KB of boxes below 0x8000 with 4 KB to spare for static LDS
 constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit)
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
 constexpr uint32_t kMaxLeaf = 4;
@@ -193,7 +194,8 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
 
   int kind = l->kernel == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2;
   const size_t lds = kind == 1 ? s.info.lds_bytes_brute : s.info.lds_bytes_bvh;
-  const bool resident = lds <= kLdsBudget;
+  // the LDS copy of a BVH addresses its boxes with 15 bits (pt_kernels.hip: stage_scene): 32 bytes per node, nodes first
+  const bool resident = lds <= kLdsBudget && (kind == 1 || s.n_nodes <= kCompactMaxNodes);
   hipStream_t stream = static_cast<hipStream_t>(l->stream);
   hipError_t e;
   const uint32_t which = l->kernel == PTAMD_KERNEL_AUTO ? ctx->default_kernel : l->kernel;
