@@ -76,7 +76,7 @@ constexpr size_t kLdsBudget = 64 * 1024;
 constexpr uint32_t kCompactMaxNodes = 896;   // 896 * 32 B = 28 KB of boxes below 0x8000 with 4 KB to spare for static LDS
 constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit)
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
-constexpr uint32_t kMaxLeaf = 4;
+constexpr uint32_t kMaxLeaf = 3;   // 3 beats 4 by 1.2 % now that a box test costs a third of a triangle test (scripts/gpu_knobs.sh)
 constexpr uint32_t kTicketRing = 1024;
 #ifndef PT_PERSISTENT_THREADS
 #define PT_PERSISTENT_THREADS 512
