@@ -1276,6 +1276,39 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel(const KParams p)
   p.surface[(size_t)(y - p.surf_row0) * p.width + x] = px;
 }
 
+// The same pass, four horizontally adjacent pixels per thread: the 48 bytes of a pixel group are three float4s in the
+// accumulator and in every sample plane, the four RGBA8 results one uint4.  Per-pixel arithmetic is unchanged.
+__global__ void __launch_bounds__(256) pt_resolve_kernel4(const KParams p)
+{
+  const uint32_t rows = p.row_end - p.row_begin;
+  const uint32_t groups_per_row = p.width / 4u;
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= rows * groups_per_row) return;
+  const uint32_t x0 = (g % groups_per_row) * 4u, y = p.row_begin + g / groups_per_row;
+  const size_t ti = (size_t)(p.height - y - 1u - p.tfb_row0) * p.width + x0;
+  float4* tp = reinterpret_cast<float4*>(p.tfb + ti * 3);
+  float4 a = tp[0], b = tp[1], c = tp[2];
+  float t[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+  const float is_static = (float)p.is_static;
+  for (uint32_t k = 0; k < p.sample_count; ++k) {
+    const float4* sp = reinterpret_cast<const float4*>(p.samples_out + (((size_t)k * rows + (y - p.row_begin)) * p.width + x0) * 3);
+    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
+    const float sv[12] = { s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w };
+    for (int i = 0; i < 12; ++i) { t[i] = t[i] * is_static; t[i] = t[i] + sv[i]; }
+  }
+  tp[0] = make_float4(t[0], t[1], t[2], t[3]); tp[1] = make_float4(t[4], t[5], t[6], t[7]); tp[2] = make_float4(t[8], t[9], t[10], t[11]);
+  uint32_t px[4];
+  const float g22 = 1.0f / 2.2f;
+  for (int q = 0; q < 4; ++q) {
+    f3 rad = mk3(t[q * 3 + 0], t[q * 3 + 1], t[q * 3 + 2]) / p.frame_nb_f;
+    rad = exposure(rad);
+    rad = mk3(pt_powf(rad.x, g22), pt_powf(rad.y, g22), pt_powf(rad.z, g22));
+    rad = post_process(p.post_id, rad);
+    px[q] = (pt_f2u(rad.x * 255.0f) & 0xffu) | ((pt_f2u(rad.y * 255.0f) & 0xffu) << 8) | ((pt_f2u(rad.z * 255.0f) & 0xffu) << 16);
+  }
+  *reinterpret_cast<uint4*>(p.surface + (size_t)(y - p.surf_row0) * p.width + x0) = make_uint4(px[0], px[1], px[2], px[3]);
+}
+
 // Nearest-hit query on explicit rays (tests: BVH vs brute force on the device).
 template <int KIND>
 __global__ void __launch_bounds__(256) pt_trace_rays_kernel(const KParams p, const float* rays, uint32_t n, int4* out)
@@ -1452,7 +1485,12 @@ hipError_t launch_resolve(const KParams& p, hipStream_t stream)
 {
   const uint32_t n = (p.row_end - p.row_begin) * p.width;
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(pt_resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, p);
+  // four pixels per thread with 16-byte accesses when rows are whole groups of four pixels and every row starts
+  // 16-byte aligned (48 bytes per group; hipMalloc'd buffers and band offsets in whole rows guarantee the bases)
+  const bool wide = (p.width % 4u) == 0u && ((uintptr_t)p.tfb % 16u) == 0u && ((uintptr_t)p.samples_out % 16u) == 0u &&
+                    ((uintptr_t)p.surface % 16u) == 0u;
+  if (wide) hipLaunchKernelGGL(pt_resolve_kernel4, dim3((n / 4u + 255u) / 256u), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(pt_resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 
