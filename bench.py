@@ -293,6 +293,9 @@ def main():
                          "algorithmic_bytes_per_sample": round(alg_bytes_frame / max(stats["samples"], 1), 1),
                          "compulsory_hbm_bytes_per_launch": int(compulsory_launch),
                          "compulsory_hbm_gbps": round(compulsory_launch / (kern_ms * 1e-3) / 1e9, 2),
+                         # HBM bytes the PMC counters saw for this kernel (`traffic`) over its measured duration
+                         "hbm_gbps_measured": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9, 2),
+                         "hbm_frac_measured": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "note": "traversal bytes are served from LDS, not HBM; see DESIGN.md 'Roofline'",
                          "nodes_per_ray": round(stats["nodes_visited"] / max(stats["rays"], 1), 2),
                          "tris_per_ray": round(stats["tris_tested"] / max(stats["rays"], 1), 2),
