@@ -200,7 +200,7 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
 // carries ~20 SALU exec-mask instructions per iteration (two exits, phi merges of masks) next to
 // ~35 VALU, and the rocprofv3 counters show 39 % of wave time stalled at issue.  This version
 // keeps one exec update per iteration: lanes leave the loop by clearing their exec bit when they
-// reach a leaf they hit or run off the tree.  v64..v74 are scratch (clobbered); masks live in
+// reach a leaf they hit or run off the tree.  v64..v69, v72 and v74 are scratch (clobbered); masks live in
 // compiler-allocated SGPR pairs.  Hazards: a VALU that reads an SGPR mask written by a VALU
 // compare needs 2 wait states (s_nop 1), exactly as hipcc pads it; SALU consumers are interlocked.
 PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count)
