@@ -748,6 +748,9 @@ PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes,
     } else {
       if (COMPACT) {
         const uint32_t base = (uint32_t)(uintptr_t)s_mem;
+        // box addresses are 15-bit codes: the host only launches this layout for <= kCompactMaxNodes nodes and the
+        // kernels keep no static LDS in front of s_mem; should either ever change, stop here rather than walk garbage
+        if (base + p.n_nodes * 32u > 0x8000u) __builtin_trap();
         for (uint32_t i = threadIdx.x; i < p.n_nodes; i += blockDim.x) {
           const float4 q0 = p.nodes[i * 4 + 0], q1 = p.nodes[i * 4 + 1];
           const uint4 m0 = *reinterpret_cast<const uint4*>(p.nodes + i * 4 + 2), m1 = *reinterpret_cast<const uint4*>(p.nodes + i * 4 + 3);
