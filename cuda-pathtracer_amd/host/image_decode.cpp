@@ -16,8 +16,8 @@
 // layouts) against the real stb_image compiled from /root/reference into oracle/_ref; tests/golden holds the
 // checksums for where /root/reference is absent.
 //
-// PNG is decoded by image_png.cpp.  The other formats stb_image reads (BMP, TGA, GIF, PSD, PIC, PNM, HDR) are
-// reported as undecodable; a host that needs them passes its own decoder through ptamd_host_scene_load_ex.
+// PNG is decoded by image_png.cpp, Radiance .hdr below (float path only).  The other formats stb_image reads (BMP,
+// TGA, GIF, PSD, PIC, PNM) are reported as undecodable; a host that needs them passes its own decoder through ptamd_host_scene_load_ex.
 #include "ptamd_internal.h"
 
 #include <cmath>
@@ -636,7 +636,106 @@ const float* ldr_to_linear_table() {
   return table.v;
 }
 
+// Radiance RGBE (.hdr), the one format stbi_loadf returns WITHOUT the 8-bit detour and the gamma rule
+// (stb_image.h:1209-1222, 6405-6590): header lines up to an empty one (FORMAT=32-bit_rle_rgbe required), "-Y h +X w",
+// then flat RGBE pixels (width < 8 or >= 32768) or per-scanline, per-channel run-length coding.  A pixel with a
+// non-zero exponent byte e is (r, g, b) * 2^(e - 136); three floats per pixel.  stb's oddity is kept: when a scanline
+// of an RLE-sized image does not start with the RLE marker, that pixel becomes pixel 0 and the REST of the file is read
+// as flat pixels from pixel 1 on.
+bool decode_hdr(const uint8_t* bytes, size_t n_bytes, int& w, int& h, std::vector<float>& out, std::string& err)
+{
+  const uint8_t* p = bytes; const uint8_t* end = bytes + n_bytes;
+  auto get8 = [&]() -> int { return p < end ? *p++ : 0; };
+  auto token = [&]() -> std::string {          // one header line (stb_image.h:6427-6447; a byte that ends the file is dropped)
+    std::string t;
+    int c = get8();
+    while (p < end && c != '\n') {
+      t += (char)c;
+      if (t.size() == 1023) { while (p < end && get8() != '\n') {} break; }
+      c = get8();
+    }
+    return t;
+  };
+  const std::string id = token();
+  if (id != "#?RADIANCE" && id != "#?RGBE") { err = "not HDR"; return false; }
+  bool valid = false;
+  for (;;) {
+    const std::string t = token();
+    if (t.empty()) break;
+    if (t == "FORMAT=32-bit_rle_rgbe") valid = true;
+  }
+  if (!valid) { err = "unsupported HDR format"; return false; }
+  const std::string dims = token();
+  if (dims.compare(0, 3, "-Y ") != 0) { err = "unsupported HDR data layout"; return false; }
+  char* rest = nullptr;
+  const long height = std::strtol(dims.c_str() + 3, &rest, 10);
+  while (*rest == ' ') ++rest;
+  if (std::strncmp(rest, "+X ", 3) != 0) { err = "unsupported HDR data layout"; return false; }
+  const long width = std::strtol(rest + 3, nullptr, 10);
+  if (width <= 0 || height <= 0 || (uint64_t)width * (uint64_t)height > (1ull << 28)) { err = "bad HDR size"; return false; }
+  w = (int)width; h = (int)height;
+  out.assign((size_t)w * h * 3, 0.0f);
+  auto convert = [](float* o, const uint8_t* rgbe) {
+    if (rgbe[3] != 0) {
+      const float f = (float)std::ldexp(1.0f, (int)rgbe[3] - (128 + 8));
+      o[0] = rgbe[0] * f; o[1] = rgbe[1] * f; o[2] = rgbe[2] * f;
+    } else o[0] = o[1] = o[2] = 0.0f;
+  };
+  auto flat_from = [&](size_t first_pixel) {
+    for (size_t i = first_pixel; i < (size_t)w * h; ++i) {
+      uint8_t rgbe[4];
+      for (int k = 0; k < 4; ++k) rgbe[k] = (uint8_t)get8();
+      convert(&out[i * 3], rgbe);
+    }
+  };
+  if (w < 8 || w >= 32768) { flat_from(0); return true; }
+  std::vector<uint8_t> scan((size_t)w * 4);
+  for (int j = 0; j < h; ++j) {
+    const int c1 = get8(), c2 = get8(); int len = get8();
+    if (c1 != 2 || c2 != 2 || (len & 0x80)) {
+      const uint8_t rgbe[4] = { (uint8_t)c1, (uint8_t)c2, (uint8_t)len, (uint8_t)get8() };
+      convert(&out[0], rgbe);
+      flat_from(1);
+      return true;
+    }
+    len = (len << 8) | get8();
+    if (len != w) { err = "invalid decoded scanline length"; return false; }
+    for (int k = 0; k < 4; ++k) {
+      int i = 0, nleft;
+      while ((nleft = w - i) > 0) {
+        int count = get8();
+        if (count > 128) {
+          const uint8_t value = (uint8_t)get8();
+          count -= 128;
+          if (count > nleft) { err = "bad RLE data in HDR"; return false; }
+          for (int z = 0; z < count; ++z) scan[(size_t)(i++) * 4 + k] = value;
+        } else {
+          if (count > nleft) { err = "bad RLE data in HDR"; return false; }
+          if (count == 0 && p >= end) { err = "truncated HDR"; return false; }     // (stb would spin on a truncated file)
+          for (int z = 0; z < count; ++z) scan[(size_t)(i++) * 4 + k] = (uint8_t)get8();
+        }
+      }
+    }
+    for (int i = 0; i < w; ++i) convert(&out[((size_t)j * w + i) * 3], &scan[(size_t)i * 4]);
+  }
+  return true;
+}
+
 bool load_image_float(const char* path, int* w, int* h, int* c, float** data, std::string& err) {
+  {
+    std::vector<uint8_t> bytes;
+    if (!read_file(path, bytes)) { err = "can't open file"; return false; }
+    if ((bytes.size() >= 11 && std::memcmp(bytes.data(), "#?RADIANCE\n", 11) == 0) ||
+        (bytes.size() >= 7 && std::memcmp(bytes.data(), "#?RGBE\n", 7) == 0)) {
+      std::vector<float> px; int iw = 0, ih = 0;
+      if (!decode_hdr(bytes.data(), bytes.size(), iw, ih, px, err)) return false;
+      float* out = (float*)std::malloc(px.size() * sizeof(float) + 16);
+      if (!out) { err = "out of memory"; return false; }
+      std::memcpy(out, px.data(), px.size() * sizeof(float));
+      *w = iw; *h = ih; *c = 3; *data = out;
+      return true;
+    }
+  }
   Image8 img;
   if (!load_image8(path, img, err)) return false;
   const size_t n = (size_t)img.w * img.h * img.c;

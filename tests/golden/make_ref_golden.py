@@ -7,6 +7,7 @@ they lie under /root/reference).  The fixture holds only outputs (digests and bi
   ldr_to_linear_bits    stbi_loadf's float for each 8-bit level (its pow(v/255, 2.2f); level-exact gray JPEGs)
   obj[name]             sha256 of tinyobj::LoadObj's output flattened as scene.cpp:218-262 does, per shipped OBJ
   decimal_bits          float bits tinyobj's decimal reader produces for DECIMAL_SPELLINGS
+  hdr_sha256            sha256 over stbi_loadf's output for the seeded Radiance files of test_ref_thirdparty.hdr_cases(seed=3, n=25)
   png_sha256            sha256 over stbi_load's output for the seeded PNGs of test_ref_thirdparty.png_cases(reps=2, seed=9)
   resize_sha256         sha256 over stbir_resize_float's outputs for the seeded cases of test_ref_thirdparty.resize_cases
 
@@ -112,7 +113,17 @@ if __name__ == "__main__":
         assert len(xs) == len(DECIMAL_SPELLINGS)
         out["decimal_bits"] = [int(b) for b in xs.view(np.uint32)]
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_ref_thirdparty import resize_cases, png_cases
+    from test_ref_thirdparty import resize_cases, png_cases, hdr_cases
+    h = hashlib.sha256()
+    with tempfile.TemporaryDirectory() as tmp:
+        p = os.path.join(tmp, "t.hdr")
+        for name, data in hdr_cases(seed=3, n=25):
+            with open(p, "wb") as f:
+                f.write(data)
+            img = R.stbi_loadf(p)
+            assert img is not None, name
+            h.update(np.array(img.shape, np.int32).tobytes() + img.tobytes())
+    out["hdr_sha256"] = h.hexdigest()
     h = hashlib.sha256()
     with tempfile.TemporaryDirectory() as tmp:
         p = os.path.join(tmp, "t.png")

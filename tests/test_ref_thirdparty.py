@@ -425,6 +425,77 @@ def test_png_decoder_survives_corrupt_input(P, tmp_path):
     assert ok + errors == 2 * len(PNG_KINDS) * 4 and errors > 20
 
 
+# ------------------------------------------------------------------ Radiance HDR (stbi_loadf's float path)
+
+def _rle_channel(vals, rng):
+    out, i, n = bytearray(), 0, len(vals)
+    while i < n:
+        j = i
+        while j < n and vals[j] == vals[i] and j - i < 127:
+            j += 1
+        if j - i >= 3 or rng.random() < 0.2:
+            out += bytes([128 + (j - i), int(vals[i])])
+            i = j
+        else:
+            k = min(n, i + int(rng.integers(1, 128)))
+            out += bytes([k - i]) + bytes(int(v) for v in vals[i:k])
+            i = k
+    return bytes(out)
+
+
+def make_hdr(rng, w, h, rle, ident, extra):
+    px = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    px[rng.random((h, w)) < 0.2, 3] = 0                         # zero exponent: black
+    if rng.random() < 0.5:
+        px[:, : w // 2] = px[0, 0]                              # runs
+    head = ident + b"\n" + (b"# comment\nEXPOSURE=1.0\n" if extra else b"") + b"FORMAT=32-bit_rle_rgbe\n\n" + ("-Y %d +X %d\n" % (h, w)).encode()
+    body = bytearray()
+    if rle and 8 <= w < 32768:
+        for y in range(h):
+            body += bytes([2, 2, (w >> 8) & 0xFF, w & 0xFF])
+            for k in range(4):
+                body += _rle_channel(px[y, :, k], rng)
+    else:
+        body += px.tobytes()                                    # flat pixels (also what stb falls back to mid-file)
+    return head + bytes(body)
+
+
+def hdr_cases(seed=0, n=40):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        w, h = int(rng.choice([1, 3, 7, 8, 9, 16, 33, 100, 257])), int(rng.integers(1, 20))
+        yield "hdr%d_%dx%d" % (i, w, h), make_hdr(rng, w, h, bool(rng.integers(0, 2)), [b"#?RADIANCE", b"#?RGBE"][int(rng.integers(0, 2))],
+                                               bool(rng.integers(0, 2)))
+
+
+@live
+def test_hdr_decoder_matches_stb(P, tmp_path):
+    path = str(tmp_path / "t.hdr")
+    for name, data in hdr_cases():
+        with open(path, "wb") as f:
+            f.write(data)
+        ref = R.stbi_loadf(path)
+        assert ref is not None and ref.shape[2] == 3, name
+        np.testing.assert_array_equal(P.load_image(path).view(np.uint32), ref.view(np.uint32), err_msg=name)
+
+
+def test_fixture_hdr_digest_and_errors(P, fixture, tmp_path):
+    path = str(tmp_path / "t.hdr")
+    h = hashlib.sha256()
+    for name, data in hdr_cases(seed=3, n=25):
+        with open(path, "wb") as f:
+            f.write(data)
+        img = P.load_image(path)
+        h.update(np.array(img.shape, np.int32).tobytes() + img.tobytes())
+    assert h.hexdigest() == fixture["hdr_sha256"]
+    for junk in (b"#?RADIANCE\n", b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n+Y 2 +X 2\n" + b"\0" * 16, b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 2 +X 2\n" + b"\0" * 16,
+                 b"#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 9\n\x02\x02\x00\x09\x85"):
+        with open(path, "wb") as f:
+            f.write(junk)
+        with pytest.raises(P.native.PtamdError):
+            P.load_image(path)
+
+
 # ------------------------------------------------------------------ stbir_resize_float
 
 def resize_cases():
