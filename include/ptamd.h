@@ -121,13 +121,14 @@ typedef struct ptamd_host_scene ptamd_host_scene;
 #define PTAMD_LOAD_NO_IMAGES       2u
 int  ptamd_host_scene_load(const char* scene_path, uint32_t flags, ptamd_host_scene** out);
 
-/* stbi_loadf(path, &w, &h, &nb_chan, STBI_default) replacement (material_loader.cpp:97,
- * gpu_processor.cpp:99): decodes a JPEG (baseline / extended / progressive), a PNG (every colour type, bit depth and
- * interlace mode) or a Radiance .hdr (RGBE, flat or run-length coded: 3 floats per pixel, no gamma) to w*h*nb_chan
- * floats, nb_chan as stb_image reports it (JPEG: 1 for grayscale files and 3 otherwise; PNG: 1..4; HDR: 3); 8-bit sources are linearised the way stbi_loadf does it (colour
- * channels pow(v/255, 2.2f) in single precision, the alpha of 2- and 4-channel images v/255).  The 8-bit pixels are bit-identical to stb_image
- * 2.16's (the reference's decoder): tests/test_ref_thirdparty.py.  Other formats: PTAMD_ERR_IO.
- * ptamd_image_load8 returns the 8-bit pixels (stbi_load).  Free either buffer with ptamd_image_free. */
+/* stbi_loadf(path, &w, &h, &nb_chan, STBI_default) replacement (material_loader.cpp:97, gpu_processor.cpp:99):
+ * decodes a JPEG (baseline / extended / progressive), a PNG (every colour type, bit depth and interlace mode) or a
+ * Radiance .hdr (RGBE, flat or run-length coded) to w*h*nb_chan floats, nb_chan as stb_image reports it (JPEG: 1 for
+ * grayscale files and 3 otherwise; PNG: 1..4; HDR: 3).  8-bit sources are linearised the way stbi_loadf does it
+ * (colour channels pow(v/255, 2.2f) in single precision, the alpha of 2- and 4-channel images v/255); HDR pixels are
+ * (r, g, b) * 2^(e-136), no gamma.  Pixels are bit-identical to stb_image 2.16's, the reference's decoder
+ * (tests/test_ref_thirdparty.py).  Other formats: PTAMD_ERR_IO.  ptamd_image_load8 returns the 8-bit pixels of a
+ * JPEG or PNG (stbi_load).  Free either buffer with ptamd_image_free. */
 int  ptamd_image_loadf(const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, float** data);
 int  ptamd_image_load8(const char* path, int32_t* w, int32_t* h, int32_t* nb_chan, uint8_t** data);
 void ptamd_image_free(void* data);
