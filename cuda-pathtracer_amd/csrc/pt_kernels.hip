@@ -4,11 +4,12 @@
 // together with radiance() (:41-210) and intersect() (intersection.cuh:161-246).
 //
 // Shape of the kernel (MI355X-first, not a translation of the 16x16-thread CUDA launch):
-//   * one wave64 owns an 8x8 pixel tile, four waves (a 16x16 tile) form a workgroup;
-//   * at workgroup start the whole traversal working set — 64-byte BVH nodes and 48-byte
-//     {e1,e2,v0} triangle records — is staged into LDS with 16-byte coalesced loads, so
-//     the hot loop never touches HBM/L2 (scenes that do not fit fall back to L2-resident
-//     global reads through the same code);
+//   * one wave64 owns an 8x8 pixel tile; the default (persistent) kernel keeps 24 waves per CU
+//     resident for the whole launch and hands them tiles from eight per-XCD ticket heads;
+//   * at workgroup start the whole traversal working set — BVH nodes and 48-byte {e1,e2,v0}
+//     triangle records — is staged into LDS, the nodes re-encoded on the way (32-byte boxes +
+//     16-bit hit/miss link codes, see walk_to_leaf_lds), so the hot loop never touches HBM/L2
+//     (scenes that do not fit fall back to L2-resident global reads of the plain 64-byte nodes);
 //   * nearest hit = stackless, per-octant ORDERED threaded BVH walk ("while-while": all
 //     lanes walk boxes until each has a leaf, then all lanes test triangles), conservative
 //     boxes, (t, global face index) lexicographic minimum == the reference's first-wins
