@@ -187,6 +187,12 @@ PT_DEV float xorwow_uniform(Xorwow& st)
 struct TexDesc { int32_t w, h, nb_chan; uint32_t pad; uint64_t offset; };
 
 #define PT_HEAD_STRIDE 64u
+// pixel tile of a wave in the persistent kernels: PT_TILE_W x (64 / PT_TILE_W), PT_TILE_W a power of two (8: square)
+#ifndef PT_TILE_W_LOG2
+#define PT_TILE_W_LOG2 3u
+#endif
+#define PT_TILE_W (1u << PT_TILE_W_LOG2)
+#define PT_TILE_H (64u >> PT_TILE_W_LOG2)
 struct KParams {
   // scene (device pointers)
   const float4* nodes;      // 4 float4 per BVH node

@@ -887,8 +887,8 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
           }
           tile_k = tile / p.n_tiles;
           const uint32_t tl = tile - tile_k * p.n_tiles;
-          tile_x0 = (tl % p.tiles_x) * 8u;
-          tile_y0 = p.row_begin + (tl / p.tiles_x) * 8u;
+          tile_x0 = (tl % p.tiles_x) * PT_TILE_W;
+          tile_y0 = p.row_begin + (tl / p.tiles_x) * PT_TILE_H;
           ++tile;
           qpos = 0;
         }
@@ -896,7 +896,7 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
         const uint32_t avail = 64u - qpos;
         if (idle && rank < avail) {
           const uint32_t k = qpos + rank;
-          const uint32_t x = tile_x0 + (k & 7u), y = tile_y0 + (k >> 3);
+          const uint32_t x = tile_x0 + (k & (PT_TILE_W - 1u)), y = tile_y0 + (k >> PT_TILE_W_LOG2);
           if (x < p.width && y < p.row_end) {
             path_begin(p, x, y, st, tile_k);
             idle = false;
@@ -1126,8 +1126,8 @@ __global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakern
     bool failed = false;
     while (ticket < total && !failed) {
       const uint32_t k = ticket / p.n_tiles, tl = ticket - k * p.n_tiles;
-      const uint32_t x = (tl % p.tiles_x) * 8u + (lane & 7u);
-      const uint32_t y = p.row_begin + (tl / p.tiles_x) * 8u + (lane >> 3);
+      const uint32_t x = (tl % p.tiles_x) * PT_TILE_W + (lane & (PT_TILE_W - 1u));
+      const uint32_t y = p.row_begin + (tl / p.tiles_x) * PT_TILE_H + (lane >> PT_TILE_W_LOG2);
       const bool active = x < p.width && y < p.row_end;
       Path st;
       if (active) path_begin(p, x, y, st, k);

@@ -225,8 +225,8 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     const uint32_t count = l->frame_count > 1 ? l->frame_count : 1u;
 
     const uint32_t rows = l->row_end - l->row_begin;
-    p.tiles_x = (l->width + 7u) / 8u;
-    p.n_tiles = p.tiles_x * ((rows + 7u) / 8u);
+    p.tiles_x = (l->width + PT_TILE_W - 1u) / PT_TILE_W;
+    p.n_tiles = p.tiles_x * ((rows + PT_TILE_H - 1u) / PT_TILE_H);
     if (p.n_tiles == 0) return PTAMD_OK;
     if ((uint64_t)p.n_tiles * count >= (1ull << 31)) {   // (tile, frame) tickets are 32-bit
       set_error("ptamd_raytrace: rows x width x frame_count too large for one launch (split the batch)");
