@@ -16,7 +16,7 @@ python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo 
 PTAMD_BENCH_FORCE_GATHER=1 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_gather.json 2>> $OUT/bench.err; echo "bench+gather rc=$?"; cut -c1-300 $OUT/bench_gather.json
 for k in bvh blockwise brute; do python bench.py --steps 10 --warmup 2 --kernel $k --no-cpu-baseline > $OUT/bench_$k.json 2>> $OUT/bench.err; cut -c1-260 $OUT/bench_$k.json; echo; done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kernel -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_kernel.log 2>&1; echo "rocprof rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kernel -- python3 $R/bench.py --steps 40 --warmup 4 --no-cpu-baseline > $OUT/prof_kernel.log 2>&1; echo "rocprof rc=$?"
 find $OUT/prof_kernel -name "*kernel_stats*" | head -2
 # C++ host (examples/headless_render.cpp over raytrace.hpp) must produce the same picture as the Python host
 cd $R
