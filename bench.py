@@ -298,7 +298,9 @@ def main():
                          # HBM bytes the PMC counters saw for this kernel (`traffic`) over its measured duration
                          "hbm_gbps_measured": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9, 2),
                          "hbm_frac_measured": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "note": "traversal bytes are served from LDS, not HBM; see DESIGN.md 'Roofline'",
+                         "note": "traversal bytes are served from LDS, not HBM (DESIGN.md 'Roofline'); "
+                                 + (f"{n_slots} launches run side by side, each on 1/{n_slots} of the GPU: `achieved` and `kernel_ms_per_launch` "
+                                    "are per launch, `achieved_all_launches` is the chip-wide rate" if n_slots > 1 else "one launch at a time"),
                          "nodes_per_ray": round(stats["nodes_visited"] / max(stats["rays"], 1), 2),
                          "tris_per_ray": round(stats["tris_tested"] / max(stats["rays"], 1), 2),
                          "rays_per_sample": round(stats["rays"] / max(stats["samples"], 1), 3)},
