@@ -1,34 +1,43 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark: Msamples/s (and ms/frame) at 1920x1080, 4 spp, indoor.obj.
+"""bench.py — headline benchmark: Msamples/s (and ms/frame) at 1920x1080, 4 spp, indoor.obj (BASELINE.json configs[1]).
 
-One "step" = one frame of the hot path = `spp` consecutive static launches of the megakernel
-(frame seeds 1..spp) accumulating into a zeroed temporal framebuffer, with every input
-resident in HBM before the timed region starts.  1 sample = one execution of the reference
-kernel() for one pixel.
+One "step" = one frame of the hot path = `spp` static frames of the megakernel (frame seeds 1..spp) accumulating into
+a zeroed temporal framebuffer, with every input resident in HBM before the timed region starts.  1 sample = one
+execution of the reference kernel() for one pixel.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is split into
-contiguous pixel-row bands (cuda_pathtracer_amd.tiles), each rank renders its band with
-global-coordinate seeds, and the finished RGBA8 bands are gathered with one RCCL all-gather
-per frame.  The frame is fixed, so scaling is "strong".
+N > 1: one rank per GPU.  Started as `python bench.py --gpus N` this script launches the ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, spawned before anything touches the GPU; its
+single JSON line and return code are relayed); started under torch.distributed.run it is a rank.  The frame is split
+into pixel-row bands (cuda_pathtracer_amd.tiles), each rank renders its band with global-coordinate seeds, and the
+finished RGBA8 bands are gathered with one RCCL all-gather per frame.  The frame is fixed, so scaling is "strong".
 
-Frames are pipelined: two (one GPU) or three (several GPUs) frames are in flight on separate HIP streams, each
-launch sized to its share of the GPU (ptamd_launch.machine_share), so that a frame's ramp, tail, resolve pass
-and all-gather overlap the bulk of the next one — a launch costs 0.11 ms + 0.28 ms per frame, and
-that fixed part is what the overlap hides.  All K timed steps start and finish inside the timed region.  A launch
-that shares the GPU lasts about twice its share of the step: `roofline.kernel_ms_per_launch` is that measured
-duration (it is what rocprofv3 reports too), `roofline.concurrent_launches` says how many run side by side.
---frames-in-flight 1 gives the unpipelined figure.
+The headline (`value`) issues the spp frames of a step as ONE batched launch (ptamd_launch.frame_count: same
+accumulator and surface as spp consecutive launches, bit for bit) and keeps two (one GPU) or three (several GPUs) steps
+in flight on separate HIP streams, each launch sized to its share of the GPU, so that a step's ramp, tail, resolve pass
+and all-gather overlap the bulk of the next one.  Next to it, at N = 1, the line reports
+  value_unpipelined  the same batched launch, one at a time (frames_in_flight = 1): `ms_per_frame` is its latency;
+  value_sequential   SURVEY §8-d's literal definition: spp launches per frame, one after the other, one frame at a time;
+  other_configs      BASELINE.json configs[3] and configs[4], a few steps each.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and, at N = 1,
-`cpu_baseline` (the CPU oracle timed on the host cores — a reported baseline, not the target).
+`roofline`: the megakernel is VALU-issue / lane-divergence bound (no HBM or MFMA roof is within two orders of
+magnitude: DESIGN.md §4).  bound = "valu_issue": achieved = VALU wave-instructions issued per second chip-wide during
+the timed region (instructions per launch from the committed rocprofv3 PMC passes of this same workload,
+profiles/pmc_latest.json, x concurrent launches / the live HIP-event duration of a launch); peak = 1024 SIMDs x 2.4 GHz
+/ 2 cycles per wave64 VALU instruction.  `active_lanes` (of 64) says how many lanes an issued instruction carries; HBM
+figures are secondary (`traffic`, `hbm_frac_measured`).
+
+Rank 0 prints ONE JSON line (contract in the task statement); at N = 1 it carries `cpu_baseline` (the CPU oracle timed
+on the host cores — a reported baseline, not the target).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,10 +48,12 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 4, 4
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+N_SIMDS, CLOCK_GHZ, VALU_CYCLES = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles
+VALU_PEAK_GINST = N_SIMDS * CLOCK_GHZ / VALU_CYCLES   # 1228.8 G wave-instructions/s
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -56,19 +67,34 @@ def parse_args():
     ap.add_argument("--aperture", type=float, default=None, help="override the camera aperture (configs[4]: 0.113)")
     ap.add_argument("--kernel", choices=["persistent", "split", "bvh", "blockwise", "brute"], default="persistent")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frames rendered concurrently on separate HIP streams, each with its own context and "
-                         "buffers (double buffering, as the reference double-buffers its GL renderbuffers: "
-                         "driver/interop.cpp:107-111).  0 = auto: 2 on one GPU, 3 on several GPUs (the RCCL "
-                         "all-gather of frame i overlaps the render of frames i+1, i+2); each launch is sized to 1/n of "
-                         "the GPU (ptamd_launch.machine_share) so that the launches co-reside")
+                    help="frames rendered concurrently on separate HIP streams, each with its own buffers (double "
+                         "buffering, as the reference double-buffers its GL renderbuffers: driver/interop.cpp:107-111).  "
+                         "0 = auto: 2 on one GPU, 3 on several GPUs (the RCCL all-gather of frame i overlaps the render of "
+                         "frames i+1, i+2); each launch is sized to 1/n of the GPU (ptamd_launch.machine_share)")
     ap.add_argument("--no-share", dest="share", action="store_false",
                     help="with several frames in flight, size every launch to the whole GPU instead of its 1/n share")
     ap.add_argument("--sequential", action="store_true", help="one launch per spp instead of one batched launch per frame")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="headline only: skip value_unpipelined / value_sequential / other_configs (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
-                    help="PMC-derived HBM bytes per launch written by scripts/collect_traffic.py (optional)")
-    return ap.parse_args()
+    ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_latest.json"),
+                    help="per-dispatch PMC averages of this workload written by scripts/summarize_pmc.py (optional)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------- N > 1 without a launcher: start the ranks ourselves
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE: run N ranks under torch.distributed.run as a CHILD process (this
+    process never touches the GPU, so nothing is exec'ed or forked after HIP initialisation) and relay its output."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 class _StdoutToStderr:
@@ -137,9 +163,126 @@ def cpu_baseline(hs, cube, width, height, bounces, target_seconds):
                       f"{cores} threads, {dt:.1f} s"}
 
 
+KERNEL_SYMBOL = {"persistent": "pt_megakernel_persistent", "blockwise": "pt_megakernel_blockwise",
+                 "split": "pt_megakernel_split", "bvh": "pt_megakernel", "brute": "pt_megakernel"}
+
+
+class Workload:
+    """A frame configuration on this rank: scene uploaded once, `n_slots` frames in flight (buffers + stream each)."""
+
+    def __init__(self, P, torch, dist, hs, cube, W, H, spp, B, kernel_name, n_slots, share, batched, local_rank,
+                 world=1, rank=0, gather=False):
+        self.P, self.torch, self.dist = P, torch, dist
+        self.W, self.H, self.spp, self.B = W, H, spp, B
+        self.world, self.rank = world, rank
+        self.kernel = {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
+                       "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT}[kernel_name]
+        self.batched = batched and kernel_name in ("persistent", "split") and spp > 1
+        self.n_slots = n_slots
+        self.hs = hs
+        self.dev = torch.device("cuda", local_rank)
+        self.y0, self.y1 = P.row_bands(H, world)[rank]
+        self.ctx = P.Context(local_rank)
+        self.ctx.setup_function_tables()
+        self.sid = self.ctx.upload_scene(hs)
+        self.cid = self.ctx.upload_cubemap(cube)
+        self.info = self.ctx.scene_info(self.sid)
+        self.slots = []
+        for i in range(n_slots):
+            fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(self.y0, self.y1),
+                                 band_local=True, machine_share=n_slots if (share and n_slots > 1) else 0)
+            bg = P.BandGather(H, W, world, rank, self.dev) if gather else None
+            st = torch.cuda.current_stream() if n_slots == 1 else torch.cuda.Stream(device=self.dev)
+            self.slots.append((fr, bg, st))
+        self.counter = 0
+
+    @property
+    def frames_per_launch(self):
+        return self.spp if self.batched else 1
+
+    def step(self, ev=None):
+        torch = self.torch
+        fr, bg, st = self.slots[self.counter % self.n_slots]
+        self.counter += 1
+        with torch.cuda.stream(st):
+            fr.accum.zero_()
+            if ev is not None:
+                ev[0].record(st)
+            fr.render(spp=self.spp, bounces=self.B, kernel=self.kernel, stream=st, batched=self.batched)
+            if ev is not None:
+                ev[1].record(st)
+            if bg is not None:
+                bg.gather(fr.surface)  # one RCCL all-gather of the RGBA8 bands per frame
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, steps, warmup):
+        """W untimed steps, then exactly K timed steps between barriers.  Returns (wall seconds, mean ms between the
+        HIP events that bracket one step's launches on its stream)."""
+        torch = self.torch
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        with _StdoutToStderr():  # first collective = communicator setup (and RCCL's banner)
+            for _ in range(warmup):
+                self.step()
+            self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(evs[i])
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        step_ms = sum(a.elapsed_time(b) for a, b in evs) / max(steps, 1)
+        return dt, step_ms
+
+    def trace_stats(self):
+        """Exact traversal counts of one frame (instrumented build of the same kernel, untimed)."""
+        P = self.P
+        stats = {k: 0 for k in ("rays", "nodes_visited", "tris_tested", "mesh_hits", "nmap_hits", "samples",
+                                "wave_node_iters", "idle_unstarted", "idle_finished", "idle_parked")}
+        scratch = P.FrameRenderer(self.ctx, self.sid, self.cid, self.hs.camera_struct(), self.W, self.H,
+                                  rows=(self.y0, self.y1), band_local=True)
+        for k in range(1, self.spp + 1):
+            l = self.ctx.make_launch(scratch.surface, scratch.accum, self.sid, self.cid, self.hs.camera_struct(), self.W,
+                                     self.H, frame_nb=k, bounces=self.B, rows=(self.y0, self.y1), kernel=self.kernel,
+                                     band_local_buffers=True)
+            s = self.ctx.raytrace_stats(l)
+            for key in stats:
+                stats[key] += s[key]
+        self.torch.cuda.synchronize()
+        return stats
+
+    def checksum(self):
+        return int(self.slots[0][0].surface.to(self.torch.int64).sum().item())
+
+    def close(self):
+        self.slots = []
+        self.ctx.close()
+
+
+def load_pmc(path, kernel_name, W, H, spp, B, frames_per_launch, tessellate):
+    """profiles/pmc_latest.json applies only to the workload it was collected on."""
+    try:
+        with open(path) as f:
+            pj = json.load(f)
+    except (OSError, ValueError):
+        return None
+    ok = (pj.get("kernel") == kernel_name and pj.get("workload") == f"{W}x{H}" and pj.get("spp") == spp
+          and pj.get("bounces") == B and pj.get("frames_per_launch") == frames_per_launch and tessellate == 1)
+    return pj if ok else None
+
+
 def main():
     args = parse_args()
-    import numpy as np
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
     import cuda_pathtracer_amd as P
@@ -147,10 +290,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -162,8 +302,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
-    kernel = {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
-              "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT}[args.kernel]
     hs = P.HostScene.load(args.scene)
     if args.tessellate > 1:
         hs = P.tessellate(hs, args.tessellate)
@@ -171,148 +309,131 @@ def main():
         hs.camera["aperture"] = args.aperture
     cube = P.cubemap_for_scene(hs)
     n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (3 if world > 1 else 2)
-    dev = torch.device("cuda", local_rank)
-    y0, y1 = P.row_bands(H, world)[rank]
-    batched = (not args.sequential) and args.kernel in ("persistent", "split") and spp > 1
+    gather = world > 1 or force_gather
 
-    class Slot:
-        """One frame in flight: its own context (ticket counters, sample scratch), buffers and stream."""
+    wl = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, n_slots, args.share, not args.sequential,
+                  local_rank, world, rank, gather)
+    dt, step_ms = wl.run(args.steps, args.warmup)
+    frames_per_launch = wl.frames_per_launch
+    launches_per_step = spp // frames_per_launch
+    # one step = launches_per_step megakernel launches (+ the small resolve kernel when batched) back to back on its stream
+    kern_ms = step_ms / launches_per_step
+    value = W * H * spp * args.steps / dt / 1e6
+    info = wl.info
+    stats = wl.trace_stats()
+    checksum = wl.checksum()
+    y0, y1 = wl.y0, wl.y1
+    samples_per_launch = (y1 - y0) * W * frames_per_launch
+    compulsory_launch = 28 * (y1 - y0) * W * frames_per_launch + hs.scene_bytes()
 
-        def __init__(self, use_current_stream):
-            self.ctx = P.Context(local_rank)
-            self.ctx.setup_function_tables()
-            self.sid = self.ctx.upload_scene(hs)
-            self.cid = self.ctx.upload_cubemap(cube)
-            self.fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True,
-                                      machine_share=n_slots if args.share else 0)
-            self.bg = P.BandGather(H, W, world, rank, dev) if (world > 1 or force_gather) else None
-            self.stream = torch.cuda.current_stream() if use_current_stream else torch.cuda.Stream(device=dev)
-
-    slots = [Slot(n_slots == 1) for _ in range(n_slots)]
-    ctx, sid, cid, fr, bg = slots[0].ctx, slots[0].sid, slots[0].cid, slots[0].fr, slots[0].bg
-    info = ctx.scene_info(sid)
-
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    counter = [0]
-
-    def step(i_timed=None):
-        sl = slots[counter[0] % n_slots]
-        counter[0] += 1
-        with torch.cuda.stream(sl.stream):
-            sl.fr.accum.zero_()
-            if i_timed is not None:
-                ev0[i_timed].record(sl.stream)
-            sl.fr.render(spp=spp, bounces=B, kernel=kernel, stream=sl.stream, batched=batched)
-            if i_timed is not None:
-                ev1[i_timed].record(sl.stream)
-            if sl.bg is not None:
-                sl.bg.gather(sl.fr.surface)  # one RCCL all-gather of the RGBA8 bands per frame
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with _StdoutToStderr():  # first collective = communicator setup (and RCCL's banner)
-        for _ in range(args.warmup):
-            step()
-        barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # kernel time from HIP events on the launch stream (average megakernel launch duration)
-    # one launch = `frames_per_launch` 1-spp frames (batched: all spp in one megakernel dispatch + the small
-    # resolve kernel; sequential: one frame)
-    frames_per_launch = spp if batched else 1
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(args.steps, 1) / (spp / frames_per_launch)
-
-    # exact traversal counts for the algorithmic-bytes figure (instrumented build, untimed)
-    stats = {k: 0 for k in ("rays", "nodes_visited", "tris_tested", "mesh_hits", "nmap_hits", "samples")}
-    scratch = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True)
-    for k in range(1, spp + 1):
-        l = ctx.make_launch(scratch.surface, scratch.accum, sid, cid, hs.camera_struct(), W, H, frame_nb=k,
-                            bounces=B, rows=(y0, y1), kernel=kernel, band_local_buffers=True)
-        s = ctx.raytrace_stats(l)
-        for key in stats:
-            stats[key] += s[key]
-    torch.cuda.synchronize()
-    # SURVEY §8-d: bytes/sample = 28 + 16*h_mesh + 12*h_nmap + T,
-    #   T(BVH) = nodes_visited*64 + tris_tested*48 + rays*n_lights*32 ; T(brute) = rays*(n_faces*36 + n_lights*32)
-    n_lights = info["n_lights"]
-    if kernel != P.KERNEL_BRUTE_FORCE:
-        trav = stats["nodes_visited"] * info["node_bytes"] + stats["tris_tested"] * info["tri_bytes"] + stats["rays"] * n_lights * 32
-    else:
-        trav = stats["rays"] * (info["n_faces"] * 36 + n_lights * 32)
-    alg_bytes_frame = 28 * stats["samples"] + 16 * stats["mesh_hits"] + 12 * stats["nmap_hits"] + trav
-    alg_bytes_launch = alg_bytes_frame / spp * frames_per_launch
-    achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
-    compulsory_launch = (28 * (y1 - y0) * W) * frames_per_launch + hs.scene_bytes()
-
-    checksum = int(fr.surface.to(torch.int64).sum().item())
-    samples_total = W * H * spp * args.steps
-    value = samples_total / dt / 1e6
+    extra = {}
+    is_headline = (W, H, spp, B, args.tessellate, args.aperture) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None)
+    if world == 1 and not args.no_extra and not force_gather:
+        k2 = max(4, args.steps // 2)
+        # (a) the same batched launch, one at a time: a frame's latency and the unpipelined rate
+        if n_slots > 1:
+            solo = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, 1, False, not args.sequential, local_rank)
+            sdt, s_ms = solo.run(k2, 2)
+            solo.close()
+            extra["value_unpipelined"] = round(W * H * spp * k2 / sdt / 1e6, 3)
+            extra["ms_per_frame"] = round(s_ms, 4)
+        else:
+            extra["value_unpipelined"] = round(value, 3)
+            extra["ms_per_frame"] = round(step_ms, 4)
+        # (b) SURVEY §8-d's literal metric: spp launches per frame, one frame at a time
+        if not args.sequential:
+            seq = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, 1, False, False, local_rank)
+            qdt, q_ms = seq.run(k2, 2)
+            seq.close()
+            extra["value_sequential"] = round(W * H * spp * k2 / qdt / 1e6, 3)
+            extra["ms_per_frame_sequential"] = round(q_ms, 4)
+        # (c) the other single-GPU configurations of BASELINE.json, a few steps each
+        if is_headline and args.kernel == "persistent":
+            others = []
+            for name, scene, tess, (w2, h2, s2, b2), ap, k in (
+                    ("configs[3]: indoor.obj x24^2 tessellation (256 896 triangles, L2-resident walk) 1920x1080 4 spp 4 bounces",
+                     hs, 24, (1920, 1080, 4, 4), None, 6),
+                    ("configs[4]: indoor.scene 3840x2160 16 spp 8 bounces aperture 0.113",
+                     hs, 1, (3840, 2160, 16, 8), 0.113, 3)):
+                sc = P.tessellate(scene, tess) if tess > 1 else P.HostScene.load(args.scene)
+                if ap is not None:
+                    sc.camera["aperture"] = ap
+                o = Workload(P, torch, dist, sc, P.cubemap_for_scene(sc), w2, h2, s2, b2, "persistent", 2, True, True, local_rank)
+                odt, o_ms = o.run(k, 1)
+                oi = o.info
+                o.close()
+                others.append({"workload": name, "value": round(w2 * h2 * s2 * k / odt / 1e6, 3), "unit": "Msamples/s",
+                               "steps": k, "ms_per_step": round(odt / k * 1e3, 4), "kernel_ms_per_launch": round(o_ms, 4),
+                               "frames_in_flight": 2, "faces": oi["n_faces"], "bvh_nodes": oi["n_nodes"]})
+            extra["other_configs"] = others
 
     if rank == 0:
-        traffic = None
-        if os.path.exists(args.traffic_json):
-            try:
-                with open(args.traffic_json) as f:
-                    tj = json.load(f)
-                if (tj.get("kernel") == args.kernel and tj.get("workload") == f"{W}x{H}" and args.tessellate == 1
-                        and tj.get("frames_per_launch") == frames_per_launch and tj.get("bounces") == B):
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        pmc = load_pmc(args.pmc_json, args.kernel, W, H, spp, B, frames_per_launch, args.tessellate)
+        valu_per_sample = active_lanes = traffic = None
+        if pmc is not None:
+            valu_per_sample = pmc.get("valu_insts_per_sample")
+            active_lanes = pmc.get("active_lanes")
+            if world == 1:
+                traffic = pmc.get("hbm_bytes_per_launch")
+        valu_launch = None if valu_per_sample is None else valu_per_sample * samples_per_launch
+        # chip-wide issue rate while the timed region runs: n_slots launches side by side, each lasting kern_ms
+        achieved = None if valu_launch is None else valu_launch * n_slots / (kern_ms * 1e-3) / 1e9
+        frac = None if achieved is None else achieved / VALU_PEAK_GINST
+        box_iters = stats["wave_node_iters"]
+        roof = {
+            "bound": "valu_issue", "achieved": None if achieved is None else round(achieved, 2),
+            "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s", "frac": None if frac is None else round(frac, 4),
+            "traffic": traffic,
+            "kernel": KERNEL_SYMBOL[args.kernel], "kernel_ms_per_launch": round(kern_ms, 4), "concurrent_launches": n_slots,
+            "samples_per_launch": int(samples_per_launch),
+            "valu_insts_per_launch": None if valu_launch is None else int(valu_launch),
+            "valu_insts_per_sample": valu_per_sample,
+            "active_lanes": active_lanes,   # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: lanes (of 64) per issued VALU instruction
+            "useful_lane_frac": None if (frac is None or active_lanes is None) else round(frac * active_lanes / 64.0, 4),
+            "pmc_source": None if pmc is None else pmc.get("source"),
+            "peak_note": f"{N_SIMDS} SIMDs x {CLOCK_GHZ} GHz / {VALU_CYCLES} cycles per wave64 VALU instruction "
+                         "(MI355X_MICROARCH.md: v_fma_f32 2 cyc on SIMD-32; 64 lanes x 2 flop x this = the 157.3 TFLOP/s FP32 vector peak)",
+            "hbm_peak_gbps": HBM_PEAK_GBPS,
+            "compulsory_hbm_bytes_per_launch": int(compulsory_launch),
+            "compulsory_hbm_gbps": round(compulsory_launch * n_slots / (kern_ms * 1e-3) / 1e9, 2),
+            "hbm_gbps_measured": None if traffic is None else round(traffic * n_slots / (kern_ms * 1e-3) / 1e9, 2),
+            "hbm_frac_measured": None if traffic is None else round(traffic * n_slots / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "nodes_per_ray": round(stats["nodes_visited"] / max(stats["rays"], 1), 2),
+            "tris_per_ray": round(stats["tris_tested"] / max(stats["rays"], 1), 2),
+            "rays_per_sample": round(stats["rays"] / max(stats["samples"], 1), 3),
+            # instrumented build of the same kernel: share of the box-test loop's lane slots that test a box
+            "box_loop_lane_utilisation": None if box_iters == 0 else round(stats["nodes_visited"] / (64.0 * box_iters), 4),
+        }
+        cfg_tag = ""
+        if is_headline:
+            cfg_tag = " (configs[1])" if world == 1 else " (configs[2])"
         out = {
-            "metric": "Msamples/sec at 1920x1080, 4 spp, indoor.obj",
+            "metric": f"Msamples/sec at {W}x{H}, {spp} spp, {os.path.basename(args.scene).replace('.scene', '.obj')}",
             "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_frame": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            # latency of one frame (launch -> resolved surface on its stream); with frames in flight a step completes
+            # every ms_per_step but each frame takes longer than that
+            "ms_per_frame": extra.pop("ms_per_frame", round(step_ms, 4)),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic: assets/indoor.scene (reference asset; 1x1 textures, constant env as the reference loads it on Linux)",
             "config": {"workload": f"{os.path.basename(args.scene)}" + (f" x{args.tessellate}^2 tessellation" if args.tessellate > 1 else "")
-                                   + f" {W}x{H} {spp} spp {B} bounces"
-                                   + (f" ({'configs[1]' if world == 1 else 'configs[2]'})" if (W, H, spp, B, args.tessellate, args.aperture) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None) else ""),
-                       "kernel": args.kernel, "launches_per_frame": 1 if batched else spp, "frames_per_launch": frames_per_launch, "faces": info["n_faces"], "bvh_nodes": info["n_nodes"],
-                       "frames_in_flight": n_slots,
+                                   + f" {W}x{H} {spp} spp {B} bounces" + cfg_tag,
+                       "kernel": args.kernel, "launches_per_frame": launches_per_step, "frames_per_launch": frames_per_launch,
+                       "faces": info["n_faces"], "bvh_nodes": info["n_nodes"], "frames_in_flight": n_slots,
                        "parallelism": f"rows/{world}" + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         # launches in flight co-reside (each on 1/n of the GPU): a launch lasts ~n times its share of the
-                         # step; `achieved` is per launch as defined, the chip-wide rate is n times that
-                         "concurrent_launches": n_slots, "achieved_all_launches": round(achieved * n_slots, 2),
-                         "kernel": {"persistent": "pt_megakernel_persistent", "blockwise": "pt_megakernel_blockwise", "split": "pt_megakernel_split"}.get(args.kernel, "pt_megakernel"), "kernel_ms_per_launch": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-                         "samples_per_launch": int(stats["samples"] / spp * frames_per_launch),
-                         "algorithmic_bytes_per_sample": round(alg_bytes_frame / max(stats["samples"], 1), 1),
-                         "compulsory_hbm_bytes_per_launch": int(compulsory_launch),
-                         "compulsory_hbm_gbps": round(compulsory_launch / (kern_ms * 1e-3) / 1e9, 2),
-                         # HBM bytes the PMC counters saw for this kernel (`traffic`) over its measured duration
-                         "hbm_gbps_measured": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9, 2),
-                         "hbm_frac_measured": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "note": "traversal bytes are served from LDS, not HBM (DESIGN.md 'Roofline'); "
-                                 + (f"{n_slots} launches run side by side, each on 1/{n_slots} of the GPU: `achieved` and `kernel_ms_per_launch` "
-                                    "are per launch, `achieved_all_launches` is the chip-wide rate" if n_slots > 1 else "one launch at a time"),
-                         "nodes_per_ray": round(stats["nodes_visited"] / max(stats["rays"], 1), 2),
-                         "tris_per_ray": round(stats["tris_tested"] / max(stats["rays"], 1), 2),
-                         "rays_per_sample": round(stats["rays"] / max(stats["samples"], 1), 3)},
+            "roofline": roof,
             "rgba_checksum_rank0_band": checksum,
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cube, W, H, B, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+    bg = wl.slots[0][1]
     if bg is not None and rank == 0:
         # the gathered frame must equal rank 0's own band in its rows (cheap self-check of the collective)
         frame = bg.assemble()
-        assert torch.equal(frame[y0:y1], fr.surface), "gathered frame does not contain rank 0's band"
+        assert torch.equal(frame[y0:y1], wl.slots[0][0].surface), "gathered frame does not contain rank 0's band"
     if world > 1 or force_gather:
         dist.barrier()
         dist.destroy_process_group()

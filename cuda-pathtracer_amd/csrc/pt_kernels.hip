@@ -1509,6 +1509,26 @@ hipError_t launch_resolve(const KParams& p, hipStream_t stream)
   return hipGetLastError();
 }
 
+hipError_t resolve_kernels()
+{
+  const void* fns[] = {
+    persistent_select(true, false), persistent_select(false, false), persistent_select(true, true), persistent_select(false, true),
+    split_select(true, false), split_select(false, false), blockwise_select(true, false), blockwise_select(false, false),
+    reinterpret_cast<const void*>(pt_megakernel<1, true, false, PT_TILE_THREADS>),
+    reinterpret_cast<const void*>(pt_megakernel<1, false, false, PT_TILE_THREADS>),
+    reinterpret_cast<const void*>(pt_megakernel<2, true, false, PT_TILE_THREADS>),
+    reinterpret_cast<const void*>(pt_megakernel<2, false, false, PT_TILE_THREADS>),
+    reinterpret_cast<const void*>(pt_resolve_kernel), reinterpret_cast<const void*>(pt_resolve_kernel4),
+    reinterpret_cast<const void*>(pt_trace_rays_kernel<1>), reinterpret_cast<const void*>(pt_trace_rays_kernel<2>),
+  };
+  for (const void* fn : fns) {
+    hipFuncAttributes attr;
+    hipError_t e = hipFuncGetAttributes(&attr, fn);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,
                              hipStream_t stream)
 {

@@ -22,6 +22,8 @@ hipError_t split_blocks_per_cu(bool lds_resident, size_t scene_lds_bytes, int* o
 hipError_t launch_megakernel_split(const KParams& p, bool lds_resident, size_t scene_lds_bytes, bool stats,
                                    uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_resolve(const KParams& p, hipStream_t stream);
+// Resolves every kernel entry point of the code object (setupFunctionTables' role: fail early when the device image is unusable).
+hipError_t resolve_kernels();
 hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,
                              hipStream_t stream);
 

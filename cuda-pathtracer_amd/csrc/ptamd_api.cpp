@@ -36,6 +36,8 @@ struct DeviceScene {
   float* texels = nullptr;
   uint32_t n_faces = 0, n_lights = 0, n_nodes = 0, n_materials = 0, n_textures = 0;
   uint32_t n_bvh_tris = 0; // triangle records behind the BVH leaves (>= n_faces with split references)
+  float extent = 0.0f;       // largest |coordinate| of the scene (bvh_builder.cpp)
+  float margin_floor = 0.0f; // smallest inflation of any box face: what the slab test's rounding error must stay below
   ptamd_scene_info info{};
 };
 
@@ -59,11 +61,13 @@ struct ptamd_context {
   uint32_t* d_heads = nullptr;   // kTicketRing sets of 8 ticket heads, PT_HEAD_STRIDE dwords apart (persistent kernel)
   uint32_t ticket_next = 0;
   int n_cus = 0;
-  int blocks_per_cu[2] = { -1, -1 }; // [lds_resident]
-  int bw_blocks_per_cu[2] = { -1, -1 };
-  int sp_blocks_per_cu[2] = { -1, -1 };
-  float* d_samples = nullptr; // parked samples of batched launches (grown on demand)
-  size_t samples_bytes = 0;
+  // resident workgroups per CU of the persistent kernels: depends on the scene's dynamic LDS bytes, so the cache is
+  // keyed by them ([0] persistent, [1] blockwise, [2] split)
+  struct Occupancy { size_t lds = ~(size_t)0; int blocks_per_cu = -1; } occupancy[3];
+  // parked samples of batched launches, one scratch per stream: launches on one stream are ordered, launches on
+  // different streams of one context (frames in flight, ptamd_launch.machine_share) must not share a buffer
+  struct SampleScratch { void* stream = nullptr; float* buf = nullptr; size_t bytes = 0; };
+  std::vector<SampleScratch> sample_scratch;
   uint32_t default_kernel = PTAMD_KERNEL_BVH_PERSISTENT; // what PTAMD_KERNEL_AUTO means
   uint32_t refill_min = 0; // 0 = choose per launch (see do_launch); PTAMD_REFILL_MIN pins it
   uint32_t tiles_per_ticket = 1;
@@ -78,6 +82,7 @@ constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: reso
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
 constexpr uint32_t kMaxLeaf = 3;   // 3 beats 4 by 1.2 % now that a box test costs a third of a triangle test (scripts/gpu_knobs.sh)
 constexpr uint32_t kTicketRing = 1024;
+constexpr size_t kMaxScratchStreams = 16;   // sample scratches kept per context (one per stream that batches frames)
 #ifndef PT_PERSISTENT_THREADS
 #define PT_PERSISTENT_THREADS 512
 #endif
@@ -192,13 +197,31 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   p.stats = stats ? ctx->d_stats : nullptr;
   p.error_flag = ctx->d_stats + 15;
 
-  int kind = l->kernel == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2;
+  uint32_t which = l->kernel == PTAMD_KERNEL_AUTO ? ctx->default_kernel : l->kernel;
+  // Box margins cover the slab test's rounding, (|origin| + |plane|) * 2^-22, for origins inside the scene's extent
+  // (bvh_builder.cpp).  A camera so far outside it that this bound exceeds the margin (e.g. 1e5 units from a
+  // unit-sized scene) would need wider boxes: such launches run the exhaustive face loop instead — the reference
+  // algorithm, exact for any origin.
+  const float cam_far = std::fmax(std::fabs(cam.position.x), std::fmax(std::fabs(cam.position.y), std::fabs(cam.position.z))) +
+                        std::fabs(cam.aperture);
+  const bool far_origin = !((cam_far + s.extent) * (1.0f / 4194304.0f) <= s.margin_floor);   // also true for NaN
+  if (far_origin && s.n_faces != 0) which = PTAMD_KERNEL_BRUTE_FORCE;
+  const int kind = which == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2;
   const size_t lds = kind == 1 ? s.info.lds_bytes_brute : s.info.lds_bytes_bvh;
   // the LDS copy of a BVH addresses its boxes with 15 bits (pt_kernels.hip: stage_scene): 32 bytes per node, nodes first
   const bool resident = lds <= kLdsBudget && (kind == 1 || s.n_nodes <= kCompactMaxNodes);
   hipStream_t stream = static_cast<hipStream_t>(l->stream);
   hipError_t e;
-  const uint32_t which = l->kernel == PTAMD_KERNEL_AUTO ? ctx->default_kernel : l->kernel;
+  if (far_origin && s.n_faces != 0 && l->frame_count > 1) {
+    // batched frames == consecutive launches by contract: issue them that way
+    for (uint32_t k = 0; k < l->frame_count; ++k) {
+      ptamd_launch one = *l;
+      one.frame_nb = l->frame_nb + k; one.frame_count = 1; one.kernel = PTAMD_KERNEL_BRUTE_FORCE;
+      rc = do_launch(ctx, &one, stats);
+      if (rc != PTAMD_OK) return rc;
+    }
+    return PTAMD_OK;
+  }
   if (l->frame_count > 1 && which != PTAMD_KERNEL_BVH_PERSISTENT && which != PTAMD_KERNEL_BVH_SPLIT) {
     set_error("ptamd_raytrace: frame_count > 1 needs a persistent kernel (PTAMD_KERNEL_AUTO, _BVH_PERSISTENT or _BVH_SPLIT)");
     return PTAMD_ERR_ARG;
@@ -210,11 +233,15 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     p.tiles_x = (l->width + 31u) / 32u;
     p.n_tiles = p.tiles_x * ((rows + st_rows - 1u) / st_rows);
     if (p.n_tiles == 0) return PTAMD_OK;
-    int& bpc = ctx->bw_blocks_per_cu[resident ? 1 : 0];
-    if (bpc < 0) {
-      e = blockwise_blocks_per_cu(resident, lds, &bpc);
-      if (e != hipSuccess || bpc < 1) { bpc = -1; return hip_fail("occupancy query of the blockwise kernel", e); }
+    ptamd_context::Occupancy& occ = ctx->occupancy[1];
+    const size_t occ_key = resident ? lds : 0;
+    if (occ.blocks_per_cu < 0 || occ.lds != occ_key) {
+      int q = -1;
+      e = blockwise_blocks_per_cu(resident, lds, &q);
+      if (e != hipSuccess || q < 1) { occ.blocks_per_cu = -1; return hip_fail("occupancy query of the blockwise kernel", e); }
+      occ.blocks_per_cu = q; occ.lds = occ_key;
     }
+    const int bpc = occ.blocks_per_cu;
     uint32_t n_blocks = (uint32_t)ctx->n_cus * (uint32_t)bpc;
     if (n_blocks > p.n_tiles) n_blocks = p.n_tiles;
     p.tile_counter = ctx->d_tickets + (ctx->ticket_next++ % kTicketRing);
@@ -232,11 +259,15 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       set_error("ptamd_raytrace: rows x width x frame_count too large for one launch (split the batch)");
       return PTAMD_ERR_LIMIT;
     }
-    int& bpc = split ? ctx->sp_blocks_per_cu[resident ? 1 : 0] : ctx->blocks_per_cu[resident ? 1 : 0];
-    if (bpc < 0) {
-      e = split ? split_blocks_per_cu(resident, lds, &bpc) : persistent_blocks_per_cu(resident, lds, &bpc);
-      if (e != hipSuccess || bpc < 1) { bpc = -1; return hip_fail("occupancy query of the persistent kernel", e); }
+    ptamd_context::Occupancy& occ = ctx->occupancy[split ? 2 : 0];
+    const size_t occ_key = resident ? lds : 0;
+    if (occ.blocks_per_cu < 0 || occ.lds != occ_key) {
+      int q = -1;
+      e = split ? split_blocks_per_cu(resident, lds, &q) : persistent_blocks_per_cu(resident, lds, &q);
+      if (e != hipSuccess || q < 1) { occ.blocks_per_cu = -1; return hip_fail("occupancy query of the persistent kernel", e); }
+      occ.blocks_per_cu = q; occ.lds = occ_key;
     }
+    const int bpc = occ.blocks_per_cu;
     // waves that take tile tickets: every wave of a persistent block, the shader waves of a split block
     const uint32_t waves_per_block = split ? split_shader_waves() : kPersistentThreads / 64u;
     uint32_t n_blocks = (uint32_t)ctx->n_cus * (uint32_t)bpc;
@@ -251,14 +282,28 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       // seeds of frames frame_nb+1.. are hashed on the device; the tonemap uses the last frame number
       p.frame_nb_f = (float)(int)(l->frame_nb + count - 1u);
       const size_t need = (size_t)count * rows * l->width * 3u * sizeof(float);
-      if (need > ctx->samples_bytes) {
-        PT_HIP(hipStreamSynchronize(stream)); // earlier launches may still use the old buffer
-        (void)hipFree(ctx->d_samples);
-        ctx->d_samples = nullptr; ctx->samples_bytes = 0;
-        PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_samples), need));
-        ctx->samples_bytes = need;
+      ptamd_context::SampleScratch* sc = nullptr;
+      for (auto& c : ctx->sample_scratch) if (c.stream == l->stream) sc = &c;
+      if (!sc) {
+        if (ctx->sample_scratch.size() >= kMaxScratchStreams) {
+          // a host cycling through short-lived streams: drop every scratch once nothing can be using them
+          PT_HIP(hipDeviceSynchronize());
+          for (auto& c : ctx->sample_scratch) (void)hipFree(c.buf);
+          ctx->sample_scratch.clear();
+        }
+        ctx->sample_scratch.emplace_back();
+        sc = &ctx->sample_scratch.back();
+        sc->stream = l->stream;
       }
-      p.samples_out = ctx->d_samples;
+      if (need > sc->bytes) {
+        // only launches of this stream ever used the old buffer (the default stream also waits for the others)
+        PT_HIP(hipStreamSynchronize(stream));
+        (void)hipFree(sc->buf);
+        sc->buf = nullptr; sc->bytes = 0;
+        PT_HIP(hipMalloc(reinterpret_cast<void**>(&sc->buf), need));
+        sc->bytes = need;
+      }
+      p.samples_out = sc->buf;
     }
     if (l->machine_share > 1u) n_blocks = n_blocks / l->machine_share > 0u ? n_blocks / l->machine_share : 1u;
     const uint32_t n_tickets = (p.n_tiles * count + tiles_per_ticket - 1u) / tiles_per_ticket;
@@ -352,7 +397,7 @@ void ptamd_destroy(ptamd_context* ctx)
   (void)hipFree(ctx->d_stats);
   (void)hipFree(ctx->d_tickets);
   (void)hipFree(ctx->d_heads);
-  (void)hipFree(ctx->d_samples);
+  for (auto& c : ctx->sample_scratch) (void)hipFree(c.buf);
   delete ctx;
 }
 
@@ -433,6 +478,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   PT_HIP(hipSetDevice(ctx->device));
   DeviceScene d;
   d.n_faces = sc->n_faces; d.n_lights = sc->n_lights; d.n_nodes = bvh.n_nodes; d.n_bvh_tris = bvh.n_tris;
+  d.extent = bvh.extent; d.margin_floor = bvh.margin_floor;
   d.n_materials = sc->n_materials; d.n_textures = sc->n_textures;
   if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
       (rc = upload(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4)) ||
@@ -472,6 +518,10 @@ int ptamd_setup_function_tables(ptamd_context* ctx)
 {
   if (!ctx) { set_error("ptamd_setup_function_tables: null context"); return PTAMD_ERR_ARG; }
   PT_HIP(hipSetDevice(ctx->device));
+  // resolves every kernel entry point in the gfx950 code object (hipFuncGetAttributes loads it on first use), so a
+  // missing or mismatched device image fails here, as the reference's cudaMemcpyFromSymbol calls would (raytrace.cu:362-374)
+  hipError_t e = resolve_kernels();
+  if (e != hipSuccess) return hip_fail("ptamd_setup_function_tables: device code object", e);
   return PTAMD_OK;
 }
 

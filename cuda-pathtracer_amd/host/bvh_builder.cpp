@@ -283,6 +283,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   Builder b;
   b.max_leaf = max_leaf;
   b.prims.resize(n_faces);
+  float extent = 0.0f;   // largest finite |coordinate| of the scene
   for (uint32_t i = 0; i < n_faces; ++i) {
     Prim& p = b.prims[i];
     p.face = i;
@@ -293,6 +294,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
         // NaN vertices would poison every ancestor box: keep them out of the bounds (such a
         // face can never pass Moller-Trumbore either way)
         if (v[a] == v[a]) { p.box.lo[a] = std::min(p.box.lo[a], v[a]); p.box.hi[a] = std::max(p.box.hi[a], v[a]); }
+        if (std::fabs(v[a]) <= std::numeric_limits<float>::max()) extent = std::max(extent, std::fabs(v[a]));
       }
     }
     for (int a = 0; a < 3; ++a) {
@@ -347,14 +349,21 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
     }
   }
 
+  // The slab test evaluates fma(plane, 1/d, -(o/d)): its rounding error, expressed as a distance, is about
+  // (|o| + |plane|) * 2^-22 per axis.  Bounce rays start on the scene's surfaces (|o| <= extent), so every box also
+  // gets extent * 2^-20 (4x that error); a camera much farther out than the scene is the launcher's business
+  // (ptamd_api.cpp: far-origin check against Bvh::margin_floor).
+  const float origin_margin = extent * (1.0f / 1048576.0f);
+  out.extent = extent;
+  out.margin_floor = margin + origin_margin;
   uint32_t tri_cursor = 0;
   for (uint32_t k = 0; k < n_nodes; ++k) {
     const BuildNode& bn = b.nodes[order[k]];
     float* q = &out.nodes[(size_t)k * 16];
     for (int a = 0; a < 3; ++a) {
       float lo = bn.box.lo[a], hi = bn.box.hi[a];
-      q[a] = lo - (margin + std::fabs(lo) * 1e-6f);
-      q[4 + a] = hi + (margin + std::fabs(hi) * 1e-6f);
+      q[a] = lo - (margin + origin_margin + std::fabs(lo) * 1e-6f);
+      q[4 + a] = hi + (margin + origin_margin + std::fabs(hi) * 1e-6f);
     }
     uint32_t info = 0, child = 0;
     if (bn.left < 0) {

@@ -65,6 +65,8 @@ struct Bvh {
   std::vector<float> tris;       // 12 floats per triangle, leaf-major
   uint32_t n_nodes = 0, n_leaves = 0, max_leaf = 0, depth = 0;
   uint32_t n_tris = 0;           // triangle records (>= faces when references were split)
+  float extent = 0.0f;           // largest |coordinate| of the scene
+  float margin_floor = 0.0f;     // smallest inflation any box face received (absolute margin + extent * 2^-20)
 };
 
 

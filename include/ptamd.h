@@ -184,7 +184,8 @@ int ptamd_upload_cubemap(ptamd_context* ctx, const float* faces, uint32_t size, 
 
 /* setupFunctionTables() (raytrace.cu:360-375).  The reference copies four device
  * function pointers to the host; here post-process dispatch is a switch inside the
- * kernel, so this only validates that the device code object is loadable. */
+ * kernel, so this resolves every kernel entry point of the gfx950 code object
+ * (hipFuncGetAttributes) and fails with PTAMD_ERR_HIP when the device image cannot be used. */
 int ptamd_setup_function_tables(ptamd_context* ctx);
 
 /* ---- the hot path ---------------------------------------------------------------------
@@ -231,7 +232,10 @@ typedef struct {
                                   as N consecutive calls, bit for bit; intermediate surfaces are not produced */
   uint32_t machine_share;      /* persistent kernels: 0 or 1 = size the grid to the whole GPU; k > 1 = to 1/k of it, so that
                                   k launches in flight (one per stream) co-reside instead of queueing behind each other —
-                                  what a multi-GPU host does with its small per-GPU bands (results do not depend on it) */
+                                  what a multi-GPU host does with its small per-GPU bands (results do not depend on it).
+                                  Launches in flight on different streams may share one context: batched launches park
+                                  their samples in a per-stream scratch owned by the context.  Calls on one context must
+                                  still come from one host thread at a time (as for the reference's raytrace()) */
 } ptamd_launch;
 
 int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch);

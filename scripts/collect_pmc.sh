@@ -1,10 +1,14 @@
 #!/bin/bash
-# PMC passes (separate runs, --pmc only: no trace domains mixed in) over a short bench run.
+# PMC passes (separate runs, --pmc only: no trace domains mixed in) over a short headline-only bench run
+# (`--no-extra`: every profiled megakernel dispatch is a launch of the headline configuration).
+#   bash scripts/collect_pmc.sh [kernel] [extra bench args...]   ->  gpurun_out/pmc_summary_<kernel>.json, gpurun_out/pmc_latest.json
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc
-KERNEL=${1:-bvh}
+KERNEL=${1:-persistent}
+shift
 mkdir -p $OUT
+rm -rf $OUT/pass*
 cd /tmp && export TMPDIR=/tmp
 i=0
 for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
@@ -12,9 +16,7 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS" \
            "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernel $KERNEL > $OUT/pass$i.log 2>&1
+  rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --kernel $KERNEL "$@" > $OUT/pass$i.log 2>&1
   echo "pass $i ($SET) rc=$?"
 done
-python3 $R/scripts/summarize_pmc.py $OUT $KERNEL > $R/gpurun_out/pmc_summary_$KERNEL.json
-FPL=1; if [ "$KERNEL" = "persistent" ]; then FPL=4; fi   # bench.py batches the 4 spp of a frame into one persistent launch
-python3 $R/scripts/collect_traffic.py $R/gpurun_out/pmc_summary_$KERNEL.json $KERNEL $R/gpurun_out/traffic_$KERNEL.json $FPL
+python3 $R/scripts/summarize_pmc.py $OUT $KERNEL $R/gpurun_out/pmc_latest.json "$@" > $R/gpurun_out/pmc_summary_$KERNEL.json

@@ -65,3 +65,64 @@ def test_two_rank_split_and_gather_equals_single_rank(P, O, indoor, tmp_path):
     _, want = O.render(O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera), 64, 37,
                        spp=2, bounces=3)
     np.testing.assert_array_equal(frame, want)
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no WORLD_SIZE: how a driver without a launcher calls it) must start two ranks by itself.
+    On a GPU-less box the ranks then stop at "needs a GPU" — not at a refusal to start."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the self-launch is exercised by the multi-GPU bench itself")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]      # both ranks got as far as the device check
+    assert "must be launched with" not in r.stderr and r.stdout.strip() == ""
+
+
+GPU_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path[:0] = [{root!r}]
+    import numpy as np, torch, torch.distributed as dist
+    import cuda_pathtracer_amd as P
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    W, H, spp, B = 1920, 1080, 4, 4
+    hs = P.HostScene.load(os.path.join({root!r}, "assets", "indoor.scene"))
+    cube = P.cubemap_for_scene(hs)
+    bg = P.BandGather(H, W, world, rank, torch.device("cpu"))
+    y0, y1 = bg.bands[rank]
+    with P.Context(0) as ctx:                                  # both ranks share the box's one GPU
+        ctx.setup_function_tables()
+        sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(cube)
+        fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True, machine_share=3)
+        fr.render(spp=spp, bounces=B, batched=True)
+        torch.cuda.synchronize()
+        bg.gather(fr.surface.cpu())
+        if rank == 0:
+            full = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H)
+            full.render(spp=spp, bounces=B)
+            torch.cuda.synchronize()
+            np.save({out!r}, np.stack([bg.assemble().numpy(), full.surface.cpu().numpy()]))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+@pytest.mark.gpu
+def test_two_rank_device_render_and_gather_equals_one_gpu_frame(tmp_path):
+    """World size 2 with the DEVICE renderer: two ranks (sharing the box's one GPU; RCCL refuses two ranks on one
+    device, so the collective runs over gloo) render their row bands of the headline frame as bench.py does at N > 1
+    (band-local buffers, batched launch on a share of the GPU) and gather them; the assembled frame must equal the
+    frame one rank renders alone, bit for bit."""
+    out = str(tmp_path / "frames.npy")
+    script = tmp_path / "gpu_worker.py"
+    script.write_text(GPU_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29519", str(script)], env=env, cwd=ROOT,
+                          timeout=900)
+    both = np.load(out)
+    np.testing.assert_array_equal(both[0], both[1])
+    assert both[0][..., :3].any()
