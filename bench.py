@@ -65,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "indoor.scene"))
     ap.add_argument("--tessellate", type=int, default=1, help="split every face into n*n (24 -> ~257k tris, configs[3])")
     ap.add_argument("--aperture", type=float, default=None, help="override the camera aperture (configs[4]: 0.113)")
-    ap.add_argument("--kernel", choices=["persistent", "split", "bvh", "blockwise", "brute"], default="persistent")
+    ap.add_argument("--kernel", choices=["restart", "persistent", "split", "bvh", "blockwise", "brute"], default="restart")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate HIP streams, each with its own buffers (double "
                          "buffering, as the reference double-buffers its GL renderbuffers: driver/interop.cpp:107-111).  "
@@ -163,7 +163,7 @@ def cpu_baseline(hs, cube, width, height, bounces, target_seconds):
                       f"{cores} threads, {dt:.1f} s"}
 
 
-KERNEL_SYMBOL = {"persistent": "pt_megakernel_persistent", "blockwise": "pt_megakernel_blockwise",
+KERNEL_SYMBOL = {"persistent": "pt_megakernel_persistent", "restart": "pt_megakernel_restart", "blockwise": "pt_megakernel_blockwise",
                  "split": "pt_megakernel_split", "bvh": "pt_megakernel", "brute": "pt_megakernel"}
 
 
@@ -176,8 +176,8 @@ class Workload:
         self.W, self.H, self.spp, self.B = W, H, spp, B
         self.world, self.rank = world, rank
         self.kernel = {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
-                       "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT}[kernel_name]
-        self.batched = batched and kernel_name in ("persistent", "split") and spp > 1
+                       "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT, "restart": P.KERNEL_BVH_RESTART}[kernel_name]
+        self.batched = batched and kernel_name in ("persistent", "split", "restart") and spp > 1
         self.n_slots = n_slots
         self.hs = hs
         self.dev = torch.device("cuda", local_rank)
@@ -348,7 +348,7 @@ def main():
             extra["value_sequential"] = round(W * H * spp * k2 / qdt / 1e6, 3)
             extra["ms_per_frame_sequential"] = round(q_ms, 4)
         # (c) the other single-GPU configurations of BASELINE.json, a few steps each
-        if is_headline and args.kernel == "persistent":
+        if is_headline and args.kernel == "restart":
             others = []
             for name, scene, tess, (w2, h2, s2, b2), ap, k in (
                     ("configs[3]: indoor.obj x24^2 tessellation (256 896 triangles, L2-resident walk) 1920x1080 4 spp 4 bounces",
@@ -358,7 +358,7 @@ def main():
                 sc = P.tessellate(scene, tess) if tess > 1 else P.HostScene.load(args.scene)
                 if ap is not None:
                     sc.camera["aperture"] = ap
-                o = Workload(P, torch, dist, sc, P.cubemap_for_scene(sc), w2, h2, s2, b2, "persistent", 2, True, True, local_rank)
+                o = Workload(P, torch, dist, sc, P.cubemap_for_scene(sc), w2, h2, s2, b2, "restart", 2, True, True, local_rank)
                 odt, o_ms = o.run(k, 1)
                 oi = o.info
                 o.close()
@@ -390,6 +390,10 @@ def main():
             "valu_insts_per_sample": valu_per_sample,
             "active_lanes": active_lanes,   # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: lanes (of 64) per issued VALU instruction
             "useful_lane_frac": None if (frac is None or active_lanes is None) else round(frac * active_lanes / 64.0, 4),
+            # the same instructions against the clocks the profiled dispatch actually ran for (the chip holds ~1.8 GHz, not
+            # 2.4, under this load): share of the VALU issue slots of the launch's 1/concurrent_launches of the GPU
+            "valu_busy_at_measured_clock": None if (pmc is None or not pmc.get("gui_active_cycles_per_launch") or not pmc.get("valu_insts_per_launch"))
+            else round(pmc["valu_insts_per_launch"] * VALU_CYCLES * n_slots / (N_SIMDS * pmc["gui_active_cycles_per_launch"]), 4),
             "pmc_source": None if pmc is None else pmc.get("source"),
             "peak_note": f"{N_SIMDS} SIMDs x {CLOCK_GHZ} GHz / {VALU_CYCLES} cycles per wave64 VALU instruction "
                          "(MI355X_MICROARCH.md: v_fma_f32 2 cyc on SIMD-32; 64 lanes x 2 flop x this = the 157.3 TFLOP/s FP32 vector peak)",

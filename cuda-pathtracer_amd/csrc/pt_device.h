@@ -237,6 +237,10 @@ struct KParams {
   // samples_out[k][band row][x] and pt_resolve_kernel applies them to the accumulator in frame order.
   uint32_t sample_count, frame_nb0;
   float* samples_out;
+  // restart kernel: per-wave pools of fresh paths (192 float4 per wave) and the straggler threshold of a round
+  float4* pool;
+  uint32_t round_min, round_div;
+  uint32_t walk_min;   // a box phase ends once fewer lanes than this are still walking (1: when none is)
 };
 
 // one intersect() result carried through radiance()

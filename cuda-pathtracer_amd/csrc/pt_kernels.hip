@@ -56,6 +56,12 @@ namespace ptamd {
 #ifndef PT_PERSISTENT_THREADS
 #define PT_PERSISTENT_THREADS 512
 #endif
+#ifndef PT_RS_THREADS
+#define PT_RS_THREADS 512
+#endif
+#ifndef PT_RS_WAVES_PER_EU
+#define PT_RS_WAVES_PER_EU 6
+#endif
 #ifndef PT_LEAF_MIN
 #define PT_LEAF_MIN 64u /* lanes parked at a leaf that end a box phase early (64 = only when all are parked) */
 #endif
@@ -152,9 +158,11 @@ PT_DEV void walk_init(Walk& w, f3 o, f3 d, uint32_t n_nodes)
 }
 
 // Box tests until this lane holds a leaf (leaf_count != 0) or its walk is over.
+// walk_min > 1: the box phase also ends once fewer than walk_min lanes of the wave are still walking (the rest are
+// parked at a leaf or done); the walkers keep their place.
 template <bool STATS>
 PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count,
-                         uint32_t& n_nodes_visited, uint32_t& wave_node_iters)
+                         uint32_t& n_nodes_visited, uint32_t& wave_node_iters, uint32_t walk_min = 1u)
 {
   const float* links = reinterpret_cast<const float*>(nodes) + w.link_off;
   leaf_first = 0;
@@ -198,6 +206,7 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
     // leave the box phase early once PT_LEAF_MIN lanes of the wave are parked at a leaf: they
     // would otherwise idle until the slowest walker finds its own (the walkers keep their place)
     if (PT_LEAF_MIN < 64 && (uint32_t)__popcll(__ballot(1)) + PT_LEAF_MIN <= lanes_in) break;
+    if (walk_min > 1u && (uint32_t)__popcll(__ballot(1)) < walk_min) break;
   }
   w.node = node;
 }
@@ -209,7 +218,7 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
 // reach a leaf they hit or run off the tree.  v64..v69, v72 and v74 are scratch (clobbered); masks live in
 // compiler-allocated SGPR pairs.  Hazards: a VALU that reads an SGPR mask written by a VALU
 // compare needs 2 wait states (s_nop 1), exactly as hipcc pads it; SALU consumers are interlocked.
-PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count)
+PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count, uint32_t walk_min = 1u)
 {
   // COMPACT LDS nodes (stage_scene), two arrays of 32-byte records, N nodes each:
   //   boxes[n] at lds_nodes + 32 n:          dwords 0..3 lo.xyz hi.x | 4..5 hi.yz | 6 leaf word
@@ -223,6 +232,7 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
   uint32_t state = w.node == PT_END ? 0xFFFFu : lds_nodes + (w.node << 5);
   const uint32_t lnk = w.n_nodes * 32u + w.oct * 4u;        // from a node's box to its link word for this ray's octant
   unsigned long long save;
+  uint32_t walkers;   // lanes still in the box loop; the loop runs while walkers >= walk_min (walk_min 1: until none is left)
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
 #ifdef PT_WALK_PRIO
@@ -260,20 +270,24 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
       "v_cndmask_b32_sdwa %[st], v72, v72, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
       "v_cmp_gt_u32 vcc, 0x8000, %[st]\n\t"            // a node address: keep walking (else parked at a leaf, or done)
       "s_and_b64 exec, exec, vcc\n\t"
-      "s_cbranch_execnz 1b\n\t"
+      "s_bcnt1_i32_b64 %[walkers], exec\n\t"
+      "s_cmp_ge_u32 %[walkers], %[wmin]\n\t"
+      "s_cbranch_scc1 1b\n\t"
       "2:\n\t"
       "s_mov_b64 exec, %[save]\n\t"
 #ifdef PT_WALK_PRIO
       "s_setprio 0\n\t"
 #endif
-      : [st] "+v"(state), [save] "=&s"(save)
-      : [lnk] "v"(lnk), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
+      : [st] "+v"(state), [save] "=&s"(save), [walkers] "=&s"(walkers)
+      : [wmin] "s"(walk_min), [lnk] "v"(lnk), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
         [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t)
       : "v64", "v65", "v66", "v67", "v68", "v69", "v72", "v74", "vcc", "scc", "memory");
   leaf_first = 0u;
   leaf_count = 0u;
   if (state == 0xFFFFu) {
     w.node = PT_END;
+  } else if (state < 0x8000u) {                              // still walking when the phase ended (walk_min > 1)
+    w.node = (state - lds_nodes) >> 5;
   } else {                                                   // parked: 0x8000 | (address of the leaf's node >> 1)
     typedef const __attribute__((address_space(3))) uint32_t* LdsU32;
     const uint32_t leaf_addr = (state & 0x7FFFu) << 1;
@@ -925,6 +939,198 @@ __global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER
   flush_counters<STATS>(p, cnt, samples);
 }
 
+// ---------------------------------------------------------------- the megakernel, restart form
+
+// Persistent waves whose lanes are asynchronous at the level of the WALK ("wavefront-level restart").
+//
+// Measured on MI355X (profiles/r02_*): the persistent kernel saturates VALU issue (98 % of the issue slots at the
+// clock the chip holds), with 25.6 of 64 lanes active — a wave's box-test loop runs for as long as its LONGEST walk
+// (mean 15.5 nodes per ray, ~47 wave iterations per bounce), so the only way to go faster is to issue fewer
+// wave-instructions per path.  Here a round of the bounce loop no longer waits for the stragglers:
+//   * every lane with a path walks; the round's traversal stops as soon as fewer than `round_min` lanes (or a quarter
+//     of the lanes that entered, whichever is smaller) are still unfinished;
+//   * lanes whose walk completed shade (light loop + path_post) and start their next walk in the next round; the few
+//     stragglers keep their place in the tree (next node + best hit so far: 5 registers) and simply continue, so the
+//     box loop runs for the ~80th percentile of the walk lengths instead of their maximum;
+//   * a lane whose path ended restarts at once on a fresh path.  Fresh paths come from a POOL that the wave fills 64 at
+//     a time with all lanes active (seed, generateRay, camera_dof for one whole 8x8 tile: 12 dwords per path, in a
+//     3 KiB slab private to the wave, L2-resident), so the expensive prologue never runs at partial occupancy.
+// Every sample is parked (path_finish_sample) and pt_resolve_kernel accumulates and tonemaps, also for one frame per
+// launch.  Results are bit-identical to every other variant: a path's arithmetic never depends on when it runs.
+PT_DEV void pool_store(float4* slab, uint32_t e, const Path& st)
+{
+  // plane-major: one wave-wide store of a plane is 1 KiB contiguous
+  slab[e] = make_float4(st.o.x, st.o.y, st.o.z, st.d.x);
+  slab[64u + e] = make_float4(st.d.y, st.d.z, u_as_f(st.rng.v0), u_as_f(st.rng.v1));
+  slab[128u + e] = make_float4(u_as_f(st.rng.v2), u_as_f(st.rng.v3), u_as_f(st.rng.v4), u_as_f(st.rng.d));
+}
+
+PT_DEV void pool_load(const float4* slab, uint32_t e, Path& st)
+{
+  // the slab is rewritten by this wave for every tile: read past the CU's vector L1 (it is write-through and may hold
+  // the previous tile's lines)
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f* q = reinterpret_cast<const v4f*>(slab);
+  const v4f a = __builtin_nontemporal_load(q + e);
+  const v4f b = __builtin_nontemporal_load(q + 64u + e);
+  const v4f c = __builtin_nontemporal_load(q + 128u + e);
+  st.o = mk3(a.x, a.y, a.z);
+  st.d = mk3(a.w, b.x, b.y);
+  st.rng.v0 = f_as_u(b.z); st.rng.v1 = f_as_u(b.w);
+  st.rng.v2 = f_as_u(c.x); st.rng.v3 = f_as_u(c.y); st.rng.v4 = f_as_u(c.z); st.rng.d = f_as_u(c.w);
+}
+
+// One round of the nearest-hit search for the lanes that call it: walks continue from (best, node) and the round ends
+// once fewer than min(round_min, entering lanes / round_div) are unfinished.  node == PT_END on return: finished.
+template <bool STATS, bool NODES_IN_LDS>
+PT_DEV void traverse_round(const float4* nodes, const float4* tris, uint32_t n_nodes, f3 o, f3 d, Best& best, uint32_t& node,
+                           uint32_t round_min, uint32_t round_div, uint32_t walk_min, Counters& cnt)
+{
+  Walk w;
+  walk_init(w, o, d, n_nodes);
+  w.best = best;
+  w.node = node;
+  const uint32_t n_start = (uint32_t)__popcll(__ballot(node != PT_END));
+  uint32_t t_eff = (n_start + round_div - 1u) / round_div;
+  if (t_eff > round_min) t_eff = round_min;
+  if (t_eff < 1u) t_eff = 1u;
+  if (STATS) w.alive = (uint32_t)__popcll(__ballot(1));
+  const uint32_t lds_nodes = (uint32_t)(uintptr_t)nodes;
+  for (;;) {
+    uint32_t leaf_first, leaf_count;
+    if (NODES_IN_LDS && !STATS && PT_ASM_WALK) walk_to_leaf_lds(lds_nodes, w, leaf_first, leaf_count, walk_min);
+    else walk_to_leaf<STATS>(nodes, w, leaf_first, leaf_count, cnt.nodes, cnt.wave_node_iters, walk_min);
+    if (leaf_count != 0u) walk_leaf<STATS>(tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters);
+    if ((uint32_t)__popcll(__ballot(w.node != PT_END)) < t_eff) break;
+  }
+  best = w.best;
+  node = w.node;
+  if (STATS) { cnt.idle3[0] += w.idle_unstarted; cnt.idle3[1] += w.idle_finished; cnt.idle3[2] += w.idle_parked; }
+}
+
+template <bool LDS_RESIDENT, bool STATS>
+__global__ void __launch_bounds__(PT_RS_THREADS, PT_RS_WAVES_PER_EU) pt_megakernel_restart(const KParams p)
+{
+  extern __shared__ float4 s_mem[];
+  const float4* s_nodes;
+  const float4* s_tris;
+  stage_scene<2, LDS_RESIDENT, LDS_RESIDENT && !STATS && PT_ASM_WALK>(p, s_mem, s_nodes, s_tris);
+
+  const uint32_t lane = threadIdx.x & 63u;
+  float4* slab = p.pool + (size_t)(blockIdx.x * (PT_RS_THREADS / 64u) + (threadIdx.x >> 6)) * 192u;
+  Counters cnt = {};
+  uint32_t samples = 0;
+
+  Path st;
+  st.o = st.d = st.throughput = st.acc = mk3(0.f);
+  st.rng.v0 = st.rng.v1 = st.rng.v2 = st.rng.v3 = st.rng.v4 = st.rng.d = 0;
+  st.specular_col = 0.f; st.xy = 0; st.bk = 0;
+  bool idle = true;      // this lane has no path
+  bool walking = false;  // its path is in the middle of a walk: (best, node, r1) are live
+  Best best;
+  best.t = PT_MAX_DIST; best.u = best.v = 0.f; best.idx = PT_END;
+  uint32_t node = PT_END;
+  float r1 = 0.f;
+  // wave-uniform: the pool holds the paths of ONE tile, entries [pool_rd, 64) not yet handed out
+  uint32_t pool_rd = 64u, tile_x0 = 0, tile_y0 = 0, tile_k = 0;
+  uint32_t tile = 0, tile_end = 0;
+  uint32_t ticket = blockIdx.x * (PT_RS_THREADS / 64u) + (threadIdx.x >> 6);
+  uint32_t head = blockIdx.x & 7u, dry = 0;
+  bool have_ticket = true, exhausted = false;
+
+  for (;;) {
+    // ---- restart lanes without a path from the pool; an empty pool is refilled with a whole tile, all lanes active
+    unsigned long long need = __ballot(idle);
+    while (need) {
+      if (pool_rd >= 64u) {
+        if (exhausted) break;
+        if (tile >= tile_end) {
+          const uint32_t total = p.n_tiles * p.sample_count; // (tile, frame) pairs
+          if (!have_ticket) {
+            for (;;) {
+              uint32_t t = 0;
+              if (lane == 0) t = atomicAdd(p.tile_heads + head * PT_HEAD_STRIDE, 1u);
+              t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+              ticket = p.n_static + t * 8u + head;
+              if ((unsigned long long)ticket * p.tiles_per_ticket < total) break;
+              head = (head + 1u) & 7u;
+              if (++dry == 8u) break;
+            }
+            if (dry == 8u) { exhausted = true; break; }
+          }
+          have_ticket = false;
+          tile = ticket * p.tiles_per_ticket;
+          if (tile >= total) { exhausted = true; break; }
+          tile_end = tile + p.tiles_per_ticket;
+          if (tile_end > total) tile_end = total;
+        }
+        tile_k = tile / p.n_tiles;
+        const uint32_t tl = tile - tile_k * p.n_tiles;
+        tile_x0 = (tl % p.tiles_x) * PT_TILE_W;
+        tile_y0 = p.row_begin + (tl / p.tiles_x) * PT_TILE_H;
+        ++tile;
+        {
+          const uint32_t x = tile_x0 + (lane & (PT_TILE_W - 1u)), y = tile_y0 + (lane >> PT_TILE_W_LOG2);
+          if (x < p.width && y < p.row_end) {
+            Path fresh;
+            path_begin(p, x, y, fresh, tile_k);
+            pool_store(slab, lane, fresh);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have reached L2 before any lane reads them back
+        }
+        pool_rd = 0u;
+      }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+      const uint32_t avail = 64u - pool_rd;
+      if (idle && rank < avail) {
+        const uint32_t e = pool_rd + rank;
+        const uint32_t x = tile_x0 + (e & (PT_TILE_W - 1u)), y = tile_y0 + (e >> PT_TILE_W_LOG2);
+        if (x < p.width && y < p.row_end) {   // entries of pixels outside the frame were never written: skip them
+          pool_load(slab, e, st);
+          st.throughput = mk3(1.0f);
+          st.acc = mk3(0.0f);
+          st.specular_col = 0.0f;
+          st.xy = x | (y << 16);
+          st.bk = tile_k << 16;
+          idle = false;
+          walking = false;
+        }
+      }
+      const uint32_t wanted = (uint32_t)__popcll(need);
+      pool_rd += wanted < avail ? wanted : avail;
+      need = __ballot(idle);
+    }
+    if (__ballot(!idle) == 0ull) break;
+
+    if (!idle) {
+      if (!walking) {
+        r1 = path_pre(p, st);
+        best.t = PT_MAX_DIST; best.u = 0.f; best.v = 0.f; best.idx = PT_END;
+        node = p.n_nodes ? 0u : PT_END;
+        walking = true;
+        if (STATS) cnt.rays++;
+      }
+      traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.walk_min, cnt);
+      if (STATS) {   // fetch_events: rounds of this wave; fetch_rays: walks that completed in them
+        if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) cnt.fetch_events++;
+        if (node == PT_END) cnt.fetch_rays++;
+      }
+      if (node == PT_END) {
+        Nearest n;
+        n.t = best.t; n.u = best.u; n.v = best.v; n.idx = best.idx;
+        n = nearest_lights(p, st.o, st.d, n);
+        walking = false;
+        if (path_post<STATS>(p, st, r1, n, cnt)) {
+          path_finish_sample(p, st);
+          idle = true;
+          if (STATS) samples++;
+        }
+      }
+    }
+  }
+  flush_counters<STATS>(p, cnt, samples);
+}
+
 // ---------------------------------------------------------------- the megakernel, blockwise form
 
 // Persistent WORKGROUPS with per-bounce ray compaction, octant sort and dynamic ray fetch.
@@ -1412,6 +1618,43 @@ hipError_t launch_megakernel_persistent(const KParams& p, bool lds_resident, siz
   return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_PERSISTENT_THREADS), args, lds_bytes, stream);
 }
 
+static const void* restart_select(bool lds_resident, bool stats)
+{
+  if (lds_resident)
+    return stats ? reinterpret_cast<const void*>(pt_megakernel_restart<true, true>)
+                 : reinterpret_cast<const void*>(pt_megakernel_restart<true, false>);
+  return stats ? reinterpret_cast<const void*>(pt_megakernel_restart<false, true>)
+               : reinterpret_cast<const void*>(pt_megakernel_restart<false, false>);
+}
+
+uint32_t restart_threads() { return PT_RS_THREADS; }
+
+hipError_t restart_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out)
+{
+  if (!lds_resident) lds_bytes = 0;
+  const void* fn = restart_select(lds_resident, false);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, PT_RS_THREADS, lds_bytes);
+}
+
+hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t lds_bytes, bool stats,
+                                     uint32_t n_blocks, hipStream_t stream)
+{
+  if (p.n_tiles == 0 || n_blocks == 0) return hipSuccess;
+  if (!lds_resident) lds_bytes = 0;
+  const void* fn = restart_select(lds_resident, stats);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  KParams pc = p;
+  void* args[] = { &pc };
+  return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_RS_THREADS), args, lds_bytes, stream);
+}
+
 static const void* split_select(bool lds_resident, bool stats)
 {
   if (lds_resident)
@@ -1514,6 +1757,7 @@ hipError_t resolve_kernels()
   const void* fns[] = {
     persistent_select(true, false), persistent_select(false, false), persistent_select(true, true), persistent_select(false, true),
     split_select(true, false), split_select(false, false), blockwise_select(true, false), blockwise_select(false, false),
+    restart_select(true, false), restart_select(false, false), restart_select(true, true), restart_select(false, true),
     reinterpret_cast<const void*>(pt_megakernel<1, true, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_megakernel<1, false, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_megakernel<2, true, false, PT_TILE_THREADS>),

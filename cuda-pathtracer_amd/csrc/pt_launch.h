@@ -21,6 +21,10 @@ uint32_t split_shader_waves();
 hipError_t split_blocks_per_cu(bool lds_resident, size_t scene_lds_bytes, int* out);
 hipError_t launch_megakernel_split(const KParams& p, bool lds_resident, size_t scene_lds_bytes, bool stats,
                                    uint32_t n_blocks, hipStream_t stream);
+uint32_t restart_threads();
+hipError_t restart_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out);
+hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t lds_bytes, bool stats,
+                                     uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_resolve(const KParams& p, hipStream_t stream);
 // Resolves every kernel entry point of the code object (setupFunctionTables' role: fail early when the device image is unusable).
 hipError_t resolve_kernels();

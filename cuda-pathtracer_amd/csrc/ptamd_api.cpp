@@ -62,14 +62,18 @@ struct ptamd_context {
   uint32_t ticket_next = 0;
   int n_cus = 0;
   // resident workgroups per CU of the persistent kernels: depends on the scene's dynamic LDS bytes, so the cache is
-  // keyed by them ([0] persistent, [1] blockwise, [2] split)
-  struct Occupancy { size_t lds = ~(size_t)0; int blocks_per_cu = -1; } occupancy[3];
+  // keyed by them ([0] persistent, [1] blockwise, [2] split, [3] restart)
+  struct Occupancy { size_t lds = ~(size_t)0; int blocks_per_cu = -1; } occupancy[4];
   // parked samples of batched launches, one scratch per stream: launches on one stream are ordered, launches on
   // different streams of one context (frames in flight, ptamd_launch.machine_share) must not share a buffer
   struct SampleScratch { void* stream = nullptr; float* buf = nullptr; size_t bytes = 0; };
   std::vector<SampleScratch> sample_scratch;
-  uint32_t default_kernel = PTAMD_KERNEL_BVH_PERSISTENT; // what PTAMD_KERNEL_AUTO means
+  uint32_t default_kernel = PTAMD_KERNEL_BVH_RESTART; // what PTAMD_KERNEL_AUTO means
   uint32_t refill_min = 0; // 0 = choose per launch (see do_launch); PTAMD_REFILL_MIN pins it
+  // restart kernel: a round of walks ends once fewer than min(round_min, entering lanes / round_div) lanes are unfinished
+  // measured (scripts/gpu_r2_sweep.sh, 1080p x 4 spp x 4 bounces): round_min 16-32 and walk_min 4-6 are a flat optimum
+  uint32_t round_min = 16, round_div = 4; // PTAMD_ROUND_MIN, PTAMD_ROUND_DIV
+  uint32_t walk_min = 5;                  // restart kernel: a box phase ends once fewer lanes than this still walk (PTAMD_WALK_MIN)
   uint32_t tiles_per_ticket = 1;
 };
 
@@ -149,7 +153,7 @@ int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
   if (l->bounces == 0 || l->bounces > 1024) { set_error("ptamd_raytrace: bounces out of range (1..1024)"); return PTAMD_ERR_ARG; }
   if (l->frame_count > 4096) { set_error("ptamd_raytrace: frame_count out of range (<= 4096)"); return PTAMD_ERR_ARG; }
   if (l->frame_count > 1 && l->moved) { set_error("ptamd_raytrace: batched frames must be static (moved = 0)"); return PTAMD_ERR_ARG; }
-  if (l->kernel > PTAMD_KERNEL_BVH_SPLIT) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
+  if (l->kernel > PTAMD_KERNEL_BVH_RESTART) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
   if (l->machine_share > 64) { set_error("ptamd_raytrace: machine_share out of range (<= 64)"); return PTAMD_ERR_ARG; }
   return PTAMD_OK;
 }
@@ -222,8 +226,8 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     }
     return PTAMD_OK;
   }
-  if (l->frame_count > 1 && which != PTAMD_KERNEL_BVH_PERSISTENT && which != PTAMD_KERNEL_BVH_SPLIT) {
-    set_error("ptamd_raytrace: frame_count > 1 needs a persistent kernel (PTAMD_KERNEL_AUTO, _BVH_PERSISTENT or _BVH_SPLIT)");
+  if (l->frame_count > 1 && which != PTAMD_KERNEL_BVH_PERSISTENT && which != PTAMD_KERNEL_BVH_SPLIT && which != PTAMD_KERNEL_BVH_RESTART) {
+    set_error("ptamd_raytrace: frame_count > 1 needs a persistent kernel (PTAMD_KERNEL_AUTO, _BVH_PERSISTENT, _BVH_RESTART or _BVH_SPLIT)");
     return PTAMD_ERR_ARG;
   }
   if (which == PTAMD_KERNEL_BVH_BLOCKWISE) {
@@ -247,8 +251,9 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     p.tile_counter = ctx->d_tickets + (ctx->ticket_next++ % kTicketRing);
     PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)n_blocks, 1, stream));
     e = launch_megakernel_blockwise(p, resident, lds, stats, n_blocks, stream);
-  } else if (which == PTAMD_KERNEL_BVH_PERSISTENT || which == PTAMD_KERNEL_BVH_SPLIT) {
+  } else if (which == PTAMD_KERNEL_BVH_PERSISTENT || which == PTAMD_KERNEL_BVH_SPLIT || which == PTAMD_KERNEL_BVH_RESTART) {
     const bool split = which == PTAMD_KERNEL_BVH_SPLIT;
+    const bool restart = which == PTAMD_KERNEL_BVH_RESTART;
     const uint32_t count = l->frame_count > 1 ? l->frame_count : 1u;
 
     const uint32_t rows = l->row_end - l->row_begin;
@@ -259,17 +264,18 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       set_error("ptamd_raytrace: rows x width x frame_count too large for one launch (split the batch)");
       return PTAMD_ERR_LIMIT;
     }
-    ptamd_context::Occupancy& occ = ctx->occupancy[split ? 2 : 0];
+    ptamd_context::Occupancy& occ = ctx->occupancy[split ? 2 : (restart ? 3 : 0)];
     const size_t occ_key = resident ? lds : 0;
     if (occ.blocks_per_cu < 0 || occ.lds != occ_key) {
       int q = -1;
-      e = split ? split_blocks_per_cu(resident, lds, &q) : persistent_blocks_per_cu(resident, lds, &q);
+      e = split ? split_blocks_per_cu(resident, lds, &q)
+                : (restart ? restart_blocks_per_cu(resident, lds, &q) : persistent_blocks_per_cu(resident, lds, &q));
       if (e != hipSuccess || q < 1) { occ.blocks_per_cu = -1; return hip_fail("occupancy query of the persistent kernel", e); }
       occ.blocks_per_cu = q; occ.lds = occ_key;
     }
     const int bpc = occ.blocks_per_cu;
     // waves that take tile tickets: every wave of a persistent block, the shader waves of a split block
-    const uint32_t waves_per_block = split ? split_shader_waves() : kPersistentThreads / 64u;
+    const uint32_t waves_per_block = split ? split_shader_waves() : (restart ? restart_threads() / 64u : kPersistentThreads / 64u);
     uint32_t n_blocks = (uint32_t)ctx->n_cus * (uint32_t)bpc;
     p.sample_count = count;
     p.frame_nb0 = l->frame_nb;
@@ -278,10 +284,19 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     // 6: 3.44 vs 3.92, 8: 2.89 vs 3.71); below that, whole-wave refill keeps primary rays coherent.
     p.refill_min = ctx->refill_min ? ctx->refill_min : (l->bounces >= 5 ? 16u : 64u);
     const uint32_t tiles_per_ticket = ctx->tiles_per_ticket;
-    if (count > 1) {
-      // seeds of frames frame_nb+1.. are hashed on the device; the tonemap uses the last frame number
-      p.frame_nb_f = (float)(int)(l->frame_nb + count - 1u);
-      const size_t need = (size_t)count * rows * l->width * 3u * sizeof(float);
+    if (l->machine_share > 1u) n_blocks = n_blocks / l->machine_share > 0u ? n_blocks / l->machine_share : 1u;
+    const uint32_t n_tickets = (p.n_tiles * count + tiles_per_ticket - 1u) / tiles_per_ticket;
+    const uint32_t useful = (n_tickets + waves_per_block - 1u) / waves_per_block;
+    if (n_blocks > useful) n_blocks = useful;
+    // seeds of frames frame_nb+1.. are hashed on the device; the tonemap uses the last frame number
+    if (count > 1) p.frame_nb_f = (float)(int)(l->frame_nb + count - 1u);
+    // the restart kernel parks every sample (also of a single frame: pt_resolve_kernel accumulates and tonemaps) and
+    // keeps a 3 KiB pool of fresh paths per wave
+    const bool parks = count > 1 || restart;
+    if (parks) {
+      const size_t sample_bytes = ((size_t)count * rows * l->width * 3u * sizeof(float) + 255u) & ~(size_t)255u;
+      const size_t pool_bytes = restart ? (size_t)n_blocks * waves_per_block * 192u * sizeof(float4) : 0u;
+      const size_t need = sample_bytes + pool_bytes;
       ptamd_context::SampleScratch* sc = nullptr;
       for (auto& c : ctx->sample_scratch) if (c.stream == l->stream) sc = &c;
       if (!sc) {
@@ -304,11 +319,11 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
         sc->bytes = need;
       }
       p.samples_out = sc->buf;
+      p.pool = reinterpret_cast<float4*>(reinterpret_cast<char*>(sc->buf) + sample_bytes);
     }
-    if (l->machine_share > 1u) n_blocks = n_blocks / l->machine_share > 0u ? n_blocks / l->machine_share : 1u;
-    const uint32_t n_tickets = (p.n_tiles * count + tiles_per_ticket - 1u) / tiles_per_ticket;
-    const uint32_t useful = (n_tickets + waves_per_block - 1u) / waves_per_block;
-    if (n_blocks > useful) n_blocks = useful;
+    p.round_min = ctx->round_min;
+    p.round_div = ctx->round_div;
+    p.walk_min = ctx->walk_min;
     p.tiles_per_ticket = tiles_per_ticket;
     // tickets 0..n_waves-1 are taken statically by the waves; the shared counter hands out the rest
     const uint32_t slot = ctx->ticket_next++ % kTicketRing;
@@ -320,8 +335,9 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_heads), 0, 8u * PT_HEAD_STRIDE, stream));
     }
     if (split) { p.tiles_per_ticket = 1; e = launch_megakernel_split(p, resident, lds, stats, n_blocks, stream); }
+    else if (restart) e = launch_megakernel_restart(p, resident, lds, stats, n_blocks, stream);
     else e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
-    if (e == hipSuccess && count > 1) e = launch_resolve(p, stream);
+    if (e == hipSuccess && parks) e = launch_resolve(p, stream);
   } else {
     e = launch_megakernel(p, kind, resident, lds, stats, stream);
   }
@@ -376,9 +392,21 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
     int v = std::atoi(e);
     ctx->refill_min = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
-  if (const char* e = std::getenv("PTAMD_DEFAULT_KERNEL")) { // tuning knob: 1..4
+  if (const char* e = std::getenv("PTAMD_DEFAULT_KERNEL")) { // tuning knob: 1..6
     int v = std::atoi(e);
-    if (v >= 1 && v <= 5) ctx->default_kernel = (uint32_t)v;
+    if (v >= 1 && v <= 6) ctx->default_kernel = (uint32_t)v;
+  }
+  if (const char* e = std::getenv("PTAMD_ROUND_MIN")) { // tuning knob
+    int v = std::atoi(e);
+    ctx->round_min = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+  }
+  if (const char* e = std::getenv("PTAMD_WALK_MIN")) { // tuning knob
+    int v = std::atoi(e);
+    ctx->walk_min = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+  }
+  if (const char* e = std::getenv("PTAMD_ROUND_DIV")) { // tuning knob
+    int v = std::atoi(e);
+    ctx->round_div = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
   if (const char* e = std::getenv("PTAMD_TILES_PER_TICKET")) {
     int v = std::atoi(e);

@@ -204,12 +204,15 @@ int ptamd_raytrace(ptamd_context* ctx, void* surface_rgba8, uint32_t scene_id, u
                    float* temporal_framebuffer, int32_t moved, uint32_t post_id);
 
 typedef enum {
-  PTAMD_KERNEL_AUTO = 0,          /* the shipped default: PTAMD_KERNEL_BVH_PERSISTENT */
+  PTAMD_KERNEL_AUTO = 0,          /* the shipped default: PTAMD_KERNEL_BVH_RESTART */
   PTAMD_KERNEL_BRUTE_FORCE = 1,   /* the reference algorithm: every face, LDS-staged, wave-uniform; 1 thread = 1 pixel */
   PTAMD_KERNEL_BVH = 2,           /* stackless ordered BVH walk, LDS-staged nodes + triangles; 1 thread = 1 pixel */
   PTAMD_KERNEL_BVH_PERSISTENT = 3, /* same walk in persistent waves with mid-path lane refill (ballot + mbcnt) */
   PTAMD_KERNEL_BVH_BLOCKWISE = 4, /* persistent workgroups; live rays of each bounce compacted + octant-sorted through LDS */
-  PTAMD_KERNEL_BVH_SPLIT = 5      /* shader waves own the paths, traverser waves pull their rays from LDS and restart lanes */
+  PTAMD_KERNEL_BVH_SPLIT = 5,     /* shader waves own the paths, traverser waves pull their rays from LDS and restart lanes */
+  PTAMD_KERNEL_BVH_RESTART = 6    /* persistent waves, lanes asynchronous per walk: a round ends without waiting for its few
+                                     stragglers (they keep their place in the tree), finished lanes shade, ended paths restart
+                                     at once from a pool of fresh paths that is refilled a whole tile at a time */
 } ptamd_kernel_kind;
 
 /* Explicit form used by the bench, the tests and the multi-GPU row split. */
@@ -227,7 +230,7 @@ typedef struct {
   uint32_t post_id;            /* 0 none, 1 grayscale, 2 sepia, 3 invert (raytrace.cu:327-357) */
   uint32_t kernel;             /* ptamd_kernel_kind */
   uint32_t band_local_buffers; /* 0: buffers are full-frame; 1: they hold only the row band */
-  uint32_t frame_count;        /* 0 or 1: one frame.  N > 1 (static frames, persistent kernel only): frames
+  uint32_t frame_count;        /* 0 or 1: one frame.  N > 1 (static frames, persistent kernels only): frames
                                   frame_nb .. frame_nb+N-1 in ONE launch — same accumulator and final surface
                                   as N consecutive calls, bit for bit; intermediate surfaces are not produced */
   uint32_t machine_share;      /* persistent kernels: 0 or 1 = size the grid to the whole GPU; k > 1 = to 1/k of it, so that

@@ -11,7 +11,7 @@ hs = P.HostScene.load(os.path.join(ROOT, "assets", "indoor.scene"))
 with P.Context(0) as ctx:
     sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(P.cubemap_for_scene(hs))
     fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H)
-    for name, k in (("tile", P.KERNEL_BVH), ("persistent", P.KERNEL_BVH_PERSISTENT)):
+    for name, k in (("tile", P.KERNEL_BVH), ("persistent", P.KERNEL_BVH_PERSISTENT), ("restart", P.KERNEL_BVH_RESTART)):
         fr.reset()
         l = ctx.make_launch(fr.surface, fr.accum, sid, cid, hs.camera_struct(), W, H, frame_nb=1, bounces=B, kernel=k)
         s = ctx.raytrace_stats(l)
@@ -19,3 +19,11 @@ with P.Context(0) as ctx:
         print("  box-loop lane utilisation %.3f, tri-loop lane utilisation %.3f, box iters/ray(wave) %.2f" % (
             s["nodes_visited"] / (64.0 * max(s["wave_node_iters"], 1)), s["tris_tested"] / (64.0 * max(s["wave_tri_iters"], 1)),
             s["wave_node_iters"] * 64.0 / max(s["rays"], 1)))
+        slots = 64.0 * max(s["wave_node_iters"], 1)
+        print("  box-loop lane slots: active %.3f, no ray in this call %.3f, walk over %.3f, parked at a leaf %.3f" % (
+            s["nodes_visited"] / slots, s["idle_unstarted"] / slots, s["idle_finished"] / slots, s["idle_parked"] / slots))
+        print("  per sample: box iterations (wave) %.3f, triangle iterations (wave) %.3f" % (
+            s["wave_node_iters"] / s["samples"], s["wave_tri_iters"] / s["samples"]))
+        if name == "restart":
+            print("  rounds per wave-tile %.2f, walks completed per round %.1f" % (
+                s["fetch_events"] * 64.0 / s["samples"], s["fetch_rays"] / max(s["fetch_events"], 1)))

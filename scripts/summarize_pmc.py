@@ -31,7 +31,7 @@ for f in glob.glob(os.path.join(out_dir, "pass*", "**", "*counter_collection.csv
             if len(bools) >= 2 and bools[1] == "true":      # <.., LDS_RESIDENT, STATS, ..>: skip instrumented launches
                 continue
             want = {"bvh": "pt_megakernel<", "brute": "pt_megakernel<", "persistent": "pt_megakernel_persistent<",
-                    "blockwise": "pt_megakernel_blockwise<", "split": "pt_megakernel_split<"}.get(kernel)
+                    "blockwise": "pt_megakernel_blockwise<", "split": "pt_megakernel_split<", "restart": "pt_megakernel_restart<"}.get(kernel)
             if want and want not in nm:
                 continue
             c = row["Counter_Name"]; v = float(row["Counter_Value"])
@@ -39,7 +39,7 @@ for f in glob.glob(os.path.join(out_dir, "pass*", "**", "*counter_collection.csv
             s[0] += v; s[1] += 1
 res = {c: s[0] / s[1] for c, s in acc.items()}
 res["_dispatches"] = {c: s[1] for c, s in acc.items()}
-batched = (not bargs.sequential) and kernel in ("persistent", "split") and bargs.spp > 1
+batched = (not bargs.sequential) and kernel in ("persistent", "split", "restart") and bargs.spp > 1
 fpl = bargs.spp if batched else 1
 samples = bargs.width * bargs.height * fpl
 d = {"samples_per_launch": samples}
@@ -70,6 +70,8 @@ rec = {"kernel": kernel, "workload": f"{bargs.width}x{bargs.height}", "spp": bar
        "valu_insts_per_launch": res.get("SQ_INSTS_VALU"), "valu_insts_per_sample": d.get("valu_insts_per_sample"),
        "active_lanes": d.get("valu_active_lanes_per_inst(of 64)"),
        "salu_insts_per_launch": res.get("SQ_INSTS_SALU"), "lds_insts_per_launch": res.get("SQ_INSTS_LDS"),
+       # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = shader clocks the dispatch was resident for (MI355X_MICROARCH.md, DVFS)
+       "gui_active_cycles_per_launch": None if "GRBM_GUI_ACTIVE" not in res else res["GRBM_GUI_ACTIVE"] / 8.0,
        "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
        "hbm_bytes_per_launch": None if fetch_kb is None or write_kb is None else fetch_kb * 1024 * 2 + write_kb * 1024,
        "source": "rocprofv3 --pmc passes (scripts/collect_pmc.sh), per-dispatch averages over the un-instrumented "

@@ -39,13 +39,13 @@ def assert_same(acc, rgba, ref_acc, ref_rgba, what=""):
     np.testing.assert_array_equal(rgba, ref_rgba, err_msg=what)
 
 
-KERNELS = ["persistent", "split", "blockwise", "bvh", "brute"]
+KERNELS = ["persistent", "restart", "split", "blockwise", "bvh", "brute"]
 
 
 def batched_ok():
     """frame_count > 1 needs a persistent kernel behind PTAMD_KERNEL_AUTO: under the tuning knob
     PTAMD_DEFAULT_KERNEL=1/2/4 (scripts/gpu_knobtest.sh) the batched cases do not apply."""
-    return os.environ.get("PTAMD_DEFAULT_KERNEL", "3") in ("3", "5")
+    return os.environ.get("PTAMD_DEFAULT_KERNEL", "3") in ("3", "5", "6")
 
 
 def needs_batched_default():
@@ -55,7 +55,7 @@ def needs_batched_default():
 
 def kid(P, name):
     return {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
-            "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT}[name]
+            "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT, "restart": P.KERNEL_BVH_RESTART}[name]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -167,7 +167,7 @@ def test_row_band_split_is_bit_identical(P, gpu_ctx, indoor):
     ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
     W, H, spp, B = 200, 121, 2, 4
     full_acc, full_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
-    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
+    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_RESTART, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         pa, pr = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, k, ids=ids)
         assert_same(pa, pr, full_acc, full_rgba, f"kernel {k} vs tile kernel")
     for world in (2, 3, 8):
@@ -286,7 +286,7 @@ def test_large_scene_uses_global_memory_variant(P, O, gpu_ctx):
     info = gpu_ctx.scene_info(sid)
     assert info["lds_bytes_bvh"] > 64 * 1024
     ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 48, 32, spp=2, bounces=3)
-    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
+    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_RESTART, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 3, k)
         assert_same(acc, rgba, *ref, f"global-memory BVH kernel {k}")
 
@@ -299,7 +299,7 @@ def test_full_size_properties_1080p_4spp_4bounces(P, O, gpu_ctx, indoor):
     W, H, spp, B = 1920, 1080, 4, 4
     bvh_acc, bvh_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_AUTO, ids=ids)
     # (0) persistent waves with lane refill == one-thread-per-pixel walk
-    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
+    for k in (P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_RESTART, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         t_acc, t_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, k, ids=ids)
         assert_same(bvh_acc, bvh_rgba, t_acc, t_rgba, f"1080p default kernel vs kernel {k}")
     # (1) the BVH walk returns the brute-force loop's result for every ray of every path
@@ -340,7 +340,7 @@ def test_config4_sponza_class_deep_bvh(P, O, gpu_ctx, indoor):
     assert info["lds_bytes_bvh"] > 20 * 1024 * 1024 and info["depth"] >= 18
     osc, ocam = O.OracleScene.from_host_scene(big, cube), O.camera_from_record(big.camera)
     ref = O.render(osc, ocam, 64, 36, spp=1, bounces=3)
-    for k in (P.KERNEL_AUTO, P.KERNEL_BVH, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
+    for k in (P.KERNEL_AUTO, P.KERNEL_BVH, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_RESTART, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         acc, rgba = gpu_render(P, gpu_ctx, big, cube, 64, 36, 1, 3, k, ids=ids)
         assert_same(acc, rgba, *ref, f"sponza-class kernel {k}")
     W, H, spp, B = 1920, 1080, 4, 4
@@ -464,7 +464,7 @@ def test_random_scenes_fuzz(P, O, gpu_ctx):
         W, H = int(rng.integers(1, 70)), int(rng.integers(1, 50))
         spp, B, post = int(rng.integers(1, 4)), int(rng.integers(1, 8)), int(rng.integers(0, 4))
         ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), W, H, spp=spp, bounces=B, post_id=post)
-        for kernel in ("persistent", "bvh"):
+        for kernel in ("persistent", "restart", "bvh"):
             acc, rgba = gpu_render(P, gpu_ctx, hs, cube, W, H, spp, B, kid(P, kernel), post_id=post)
             assert_same(acc, rgba, *ref, f"fuzz seed {seed} {W}x{H} spp{spp} B{B} post{post}/{kernel}")
         # the same frames as ONE batched launch on a third of the GPU (what a host with frames in flight issues)
@@ -504,7 +504,7 @@ def test_stats_are_consistent(P, O, gpu_ctx, indoor):
     l = gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), W, H, frame_nb=1, bounces=4, kernel=P.KERNEL_BVH)
     s_bvh = gpu_ctx.raytrace_stats(l)
     fr.reset()
-    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
+    for k in (P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH_RESTART, P.KERNEL_BVH_BLOCKWISE, P.KERNEL_BVH_SPLIT):
         fr.reset()
         l.kernel = k
         s_k = gpu_ctx.raytrace_stats(l)
