@@ -63,7 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--bounces", type=int, default=BOUNCES)
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "indoor.scene"))
-    ap.add_argument("--tessellate", type=int, default=1, help="split every face into n*n (24 -> ~257k tris, configs[3])")
+    ap.add_argument("--atrium", action="store_true",
+                    help="configs[3]: generate the seed-fixed Sponza-class atrium (264 832 triangles) as OBJ + MTL + .scene in a "
+                         "temporary directory and render that scene (through the same loader as any other asset)")
+    ap.add_argument("--tessellate", type=int, default=1, help="split every face into n*n (24 -> ~257k tris: round 1's configs[3] stand-in)")
     ap.add_argument("--aperture", type=float, default=None, help="override the camera aperture (configs[4]: 0.113)")
     ap.add_argument("--kernel", choices=["restart", "persistent", "split", "bvh", "blockwise", "brute"], default="restart")
     ap.add_argument("--frames-in-flight", type=int, default=0,
@@ -74,6 +77,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-share", dest="share", action="store_false",
                     help="with several frames in flight, size every launch to the whole GPU instead of its 1/n share")
     ap.add_argument("--sequential", action="store_true", help="one launch per spp instead of one batched launch per frame")
+    ap.add_argument("--rows", default=None, metavar="Y0:Y1",
+                    help="N = 1 only: render just surface rows [Y0, Y1) of the frame (one rank's band of a multi-GPU split, "
+                         "scripts/band_proxy.py); `value` then counts the band's samples")
     ap.add_argument("--no-extra", action="store_true",
                     help="headline only: skip value_unpipelined / value_sequential / other_configs (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,7 +177,7 @@ class Workload:
     """A frame configuration on this rank: scene uploaded once, `n_slots` frames in flight (buffers + stream each)."""
 
     def __init__(self, P, torch, dist, hs, cube, W, H, spp, B, kernel_name, n_slots, share, batched, local_rank,
-                 world=1, rank=0, gather=False):
+                 world=1, rank=0, gather=False, rows=None):
         self.P, self.torch, self.dist = P, torch, dist
         self.W, self.H, self.spp, self.B = W, H, spp, B
         self.world, self.rank = world, rank
@@ -181,7 +187,7 @@ class Workload:
         self.n_slots = n_slots
         self.hs = hs
         self.dev = torch.device("cuda", local_rank)
-        self.y0, self.y1 = P.row_bands(H, world)[rank]
+        self.y0, self.y1 = P.row_bands(H, world)[rank] if rows is None else rows
         self.ctx = P.Context(local_rank)
         self.ctx.setup_function_tables()
         self.sid = self.ctx.upload_scene(hs)
@@ -191,7 +197,8 @@ class Workload:
         for i in range(n_slots):
             fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(self.y0, self.y1),
                                  band_local=True, machine_share=n_slots if (share and n_slots > 1) else 0)
-            bg = P.BandGather(H, W, world, rank, self.dev) if gather else None
+            # (a --rows band is gathered as if it were the whole frame: same message size as the rank's real gather share)
+            bg = P.BandGather(H if rows is None else self.y1 - self.y0, W, world, rank, self.dev) if gather else None
             st = torch.cuda.current_stream() if n_slots == 1 else torch.cuda.Stream(device=self.dev)
             self.slots.append((fr, bg, st))
         self.counter = 0
@@ -265,7 +272,7 @@ class Workload:
         self.ctx.close()
 
 
-def load_pmc(path, kernel_name, W, H, spp, B, frames_per_launch, tessellate):
+def load_pmc(path, kernel_name, W, H, spp, B, frames_per_launch, tessellate, scene):
     """profiles/pmc_latest.json applies only to the workload it was collected on."""
     try:
         with open(path) as f:
@@ -273,7 +280,8 @@ def load_pmc(path, kernel_name, W, H, spp, B, frames_per_launch, tessellate):
     except (OSError, ValueError):
         return None
     ok = (pj.get("kernel") == kernel_name and pj.get("workload") == f"{W}x{H}" and pj.get("spp") == spp
-          and pj.get("bounces") == B and pj.get("frames_per_launch") == frames_per_launch and tessellate == 1)
+          and pj.get("bounces") == B and pj.get("frames_per_launch") == frames_per_launch and tessellate == 1
+          and pj.get("scene", "indoor.scene") == scene)
     return pj if ok else None
 
 
@@ -302,6 +310,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W, H, spp, B = args.width, args.height, args.spp, args.bounces
+    tmp_dirs = []
+
+    def atrium_scene():
+        import tempfile
+        from cuda_pathtracer_amd.synthetic import write_atrium
+        tmp_dirs.append(tempfile.TemporaryDirectory(prefix="ptamd_atrium_"))
+        return write_atrium(tmp_dirs[-1].name)
+
+    if args.atrium:
+        args.scene = atrium_scene()
     hs = P.HostScene.load(args.scene)
     if args.tessellate > 1:
         hs = P.tessellate(hs, args.tessellate)
@@ -311,14 +329,21 @@ def main():
     n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (3 if world > 1 else 2)
     gather = world > 1 or force_gather
 
+    rows = None
+    if args.rows is not None:
+        if world != 1:
+            raise SystemExit("--rows applies to one GPU only")
+        rows = tuple(int(v) for v in args.rows.split(":"))
+        if not (0 <= rows[0] < rows[1] <= H):
+            raise SystemExit("--rows Y0:Y1 must lie inside the frame")
     wl = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, n_slots, args.share, not args.sequential,
-                  local_rank, world, rank, gather)
+                  local_rank, world, rank, gather, rows)
     dt, step_ms = wl.run(args.steps, args.warmup)
     frames_per_launch = wl.frames_per_launch
     launches_per_step = spp // frames_per_launch
     # one step = launches_per_step megakernel launches (+ the small resolve kernel when batched) back to back on its stream
     kern_ms = step_ms / launches_per_step
-    value = W * H * spp * args.steps / dt / 1e6
+    value = W * (H if rows is None else rows[1] - rows[0]) * spp * args.steps / dt / 1e6
     info = wl.info
     stats = wl.trace_stats()
     checksum = wl.checksum()
@@ -327,8 +352,8 @@ def main():
     compulsory_launch = 28 * (y1 - y0) * W * frames_per_launch + hs.scene_bytes()
 
     extra = {}
-    is_headline = (W, H, spp, B, args.tessellate, args.aperture) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None)
-    if world == 1 and not args.no_extra and not force_gather:
+    is_headline = (W, H, spp, B, args.tessellate, args.aperture, args.atrium, rows) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None, False, None)
+    if world == 1 and not args.no_extra and not force_gather and rows is None:
         k2 = max(4, args.steps // 2)
         # (a) the same batched launch, one at a time: a frame's latency and the unpipelined rate
         if n_slots > 1:
@@ -350,12 +375,12 @@ def main():
         # (c) the other single-GPU configurations of BASELINE.json, a few steps each
         if is_headline and args.kernel == "restart":
             others = []
-            for name, scene, tess, (w2, h2, s2, b2), ap, k in (
-                    ("configs[3]: indoor.obj x24^2 tessellation (256 896 triangles, L2-resident walk) 1920x1080 4 spp 4 bounces",
-                     hs, 24, (1920, 1080, 4, 4), None, 6),
+            for name, scene_path, (w2, h2, s2, b2), ap, k in (
+                    ("configs[3]: atrium.obj (generated Sponza-class OBJ, 264 832 triangles, through the loader; walked from L2) "
+                     "1920x1080 4 spp 4 bounces", None, (1920, 1080, 4, 4), None, 6),
                     ("configs[4]: indoor.scene 3840x2160 16 spp 8 bounces aperture 0.113",
-                     hs, 1, (3840, 2160, 16, 8), 0.113, 3)):
-                sc = P.tessellate(scene, tess) if tess > 1 else P.HostScene.load(args.scene)
+                     args.scene, (3840, 2160, 16, 8), 0.113, 3)):
+                sc = P.HostScene.load(scene_path if scene_path is not None else atrium_scene())
                 if ap is not None:
                     sc.camera["aperture"] = ap
                 o = Workload(P, torch, dist, sc, P.cubemap_for_scene(sc), w2, h2, s2, b2, "restart", 2, True, True, local_rank)
@@ -368,7 +393,7 @@ def main():
             extra["other_configs"] = others
 
     if rank == 0:
-        pmc = load_pmc(args.pmc_json, args.kernel, W, H, spp, B, frames_per_launch, args.tessellate)
+        pmc = load_pmc(args.pmc_json, args.kernel, W, H, spp, B, frames_per_launch, args.tessellate, os.path.basename(args.scene))
         valu_per_sample = active_lanes = traffic = None
         if pmc is not None:
             valu_per_sample = pmc.get("valu_insts_per_sample")
@@ -422,7 +447,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic: assets/indoor.scene (reference asset; 1x1 textures, constant env as the reference loads it on Linux)",
             "config": {"workload": f"{os.path.basename(args.scene)}" + (f" x{args.tessellate}^2 tessellation" if args.tessellate > 1 else "")
-                                   + f" {W}x{H} {spp} spp {B} bounces" + cfg_tag,
+                                   + (" (generated, 264 832 triangles)" if args.atrium else "")
+                                   + f" {W}x{H} {spp} spp {B} bounces" + cfg_tag
+                                   + (f", rows [{rows[0]},{rows[1]}) only" if rows is not None else ""),
                        "kernel": args.kernel, "launches_per_frame": launches_per_step, "frames_per_launch": frames_per_launch,
                        "faces": info["n_faces"], "bvh_nodes": info["n_nodes"], "frames_in_flight": n_slots,
                        "parallelism": f"rows/{world}" + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
@@ -437,7 +464,8 @@ def main():
     if bg is not None and rank == 0:
         # the gathered frame must equal rank 0's own band in its rows (cheap self-check of the collective)
         frame = bg.assemble()
-        assert torch.equal(frame[y0:y1], wl.slots[0][0].surface), "gathered frame does not contain rank 0's band"
+        g0 = 0 if rows is not None else y0      # a --rows band is gathered as a frame of its own
+        assert torch.equal(frame[g0:g0 + (y1 - y0)], wl.slots[0][0].surface), "gathered frame does not contain rank 0's band"
     if world > 1 or force_gather:
         dist.barrier()
         dist.destroy_process_group()

@@ -15,6 +15,8 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=4)
 ap.add_argument("--bounces", type=int, default=4)
 ap.add_argument("--sequential", action="store_true")
+ap.add_argument("--atrium", action="store_true")
+ap.add_argument("--scene", default="indoor.scene")
 ap.add_argument("--frames-in-flight", type=int, default=0)
 bargs, _ = ap.parse_known_args(sys.argv[4:])
 
@@ -65,7 +67,7 @@ res["_kernel"] = kernel
 print(json.dumps(res, indent=1))
 
 fetch_kb, write_kb = res.get("FETCH_SIZE"), res.get("WRITE_SIZE")
-rec = {"kernel": kernel, "workload": f"{bargs.width}x{bargs.height}", "spp": bargs.spp, "bounces": bargs.bounces,
+rec = {"kernel": kernel, "scene": "atrium.scene" if bargs.atrium else os.path.basename(bargs.scene), "workload": f"{bargs.width}x{bargs.height}", "spp": bargs.spp, "bounces": bargs.bounces,
        "frames_per_launch": fpl, "samples_per_launch": samples,
        "valu_insts_per_launch": res.get("SQ_INSTS_VALU"), "valu_insts_per_sample": d.get("valu_insts_per_sample"),
        "active_lanes": d.get("valu_active_lanes_per_inst(of 64)"),

@@ -86,3 +86,53 @@ def test_cpp_host_example_compiles_and_fails_loudly_without_gpu(P, tmp_path):
     r = subprocess.run([exe, os.path.join(ROOT, "assets", "indoor.scene"), "32", "32", "1", str(tmp_path / "o.png")],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "ptamd_create" in r.stderr and not os.path.exists(str(tmp_path / "o.png"))
+
+
+def _build_multigpu_host(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "multigpu_render")
+    lib_dir = os.path.join(ROOT, "cuda-pathtracer_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "multigpu_render.cpp"), "-L" + lib_dir, "-lptamd", "-lrccl",
+                           "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+def test_cpp_multigpu_host_compiles_and_fails_loudly_without_gpu(P, tmp_path):
+    """examples/multigpu_render.cpp — the C++ N-GPU host (row bands + ncclAllGather straight from RCCL, no Python) —
+    builds against the C-ABI, HIP and RCCL; without a GPU it stops with an error and writes nothing."""
+    import subprocess
+    import torch
+    exe = _build_multigpu_host(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    if torch.cuda.is_available():
+        return
+    out = str(tmp_path / "o.png")
+    r = subprocess.run([exe, os.path.join(ROOT, "assets", "indoor.scene"), "64", "64", "2", "3", out], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr and not os.path.exists(out)
+
+
+@pytest.mark.gpu
+def test_cpp_multigpu_host_renders_and_gathers(P, tmp_path):
+    """On the GPU box (one GPU): the C++ host with --ranks 1 --check renders its band, runs the RCCL all-gather and must
+    reproduce the frame a plain full-frame launch gives; the PNG it writes equals the Python host's surface."""
+    import json
+    import subprocess
+    import numpy as np
+    import torch
+    exe = _build_multigpu_host(tmp_path)
+    out = str(tmp_path / "o.png")
+    r = subprocess.run([exe, os.path.join(ROOT, "assets", "indoor.scene"), "320", "180", "4", "4", out, "--ranks", "1",
+                        "--frames", "3", "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and "equals" in line["check"]
+    hs = P.HostScene.load(os.path.join(ROOT, "assets", "indoor.scene"))
+    with P.Context(0) as ctx:
+        sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(P.cubemap_for_scene(hs))
+        fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), 320, 180)
+        fr.render(spp=4, bounces=4)
+        torch.cuda.synchronize()
+        want = fr.surface.cpu().numpy()[:, :, :3]
+    np.testing.assert_array_equal(P.load_image8(out), want)
