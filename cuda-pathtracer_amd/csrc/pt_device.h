@@ -241,6 +241,13 @@ struct KParams {
   float4* pool;
   uint32_t round_min, round_div;
   uint32_t walk_min;   // a box phase ends once fewer lanes than this are still walking (1: when none is)
+  // four-wide walk (scenes that do not fit in LDS): 8 float4 per node, per-lane stacks in LDS with a global continuation
+  const float4* nodes4;
+  uint32_t n_nodes4;
+  uint32_t stack_lds_entries, stack_spill_entries;
+  uint32_t treelet_nodes;   // the first nodes of nodes4 (top of the tree) are staged in LDS in front of the stacks
+  uint2* stack_spill;
+  uint32_t walk_min4;
 };
 
 // one intersect() result carried through radiance()

@@ -1008,16 +1008,198 @@ PT_DEV void traverse_round(const float4* nodes, const float4* tris, uint32_t n_n
   if (STATS) { cnt.idle3[0] += w.idle_unstarted; cnt.idle3[1] += w.idle_finished; cnt.idle3[2] += w.idle_parked; }
 }
 
+// ---------------------------------------------------------------- four-wide walk (scenes that do not fit in LDS)
+
+// Measured on MI355X (profiles/r02_pmc_atrium_binary_walk.json, 264 832 triangles): the binary walk from L2 spends 70 %
+// of its wave-cycles waiting for memory — 50 dependent node loads per ray, each a full L1-miss round trip (252 cycles
+// on average; only 75 % of them hit the XCD's 4 MB L2, the rest come from the Infinity Cache).  The cure is fewer
+// round trips, not fewer bytes: a node of the wide tree (host/ptamd_internal.h: Bvh::nodes4) is ONE 128-byte line
+// holding the boxes of its four children, fetched with eight independent 16-byte loads, so one round trip tests four
+// boxes and leaves never cost a node load of their own (17.6 node visits per ray on the same scene).  Children that
+// are hit go on a per-lane stack (LDS, [entry][lane] so a wave's pushes never conflict; entries past the LDS share
+// spill to a global slab) farthest first in the node's order for the ray's octant; each entry carries its entry
+// distance and is dropped on pop when the best hit is already nearer.  Exactness as for the binary walk: conservative
+// boxes, (t, face index) minimum.
+#define PT_NONE 0xFFFFFFFFu
+#define PT_LEAF_BIT 0x80000000u
+
+struct Stack4 {
+  uint2* lds;          // this lane's column of the wave's LDS stack: entry k at lds[k * 64]
+  uint2* spill;        // global continuation: entry k >= lds_entries at spill[(k - lds_entries) * 64]
+  uint32_t lds_entries;
+  // the first `top_n` nodes of the tree (breadth-first numbering: its top levels, which every ray crosses) staged in
+  // LDS by the workgroup: a third to a half of all node visits never leave the CU
+  const float4* top;
+  uint32_t top_n;
+};
+#ifndef PT_RS4_WAVES_PER_EU
+#define PT_RS4_WAVES_PER_EU 4   /* measured on the atrium (leaf records fetched in one batch): 4 / 5 / 6 waves per SIMD = 1069 / 954 / 798 Msamples/s (5 and 6 spill) */
+#endif
+
+PT_DEV void stack4_write(const Stack4& s, uint32_t k, uint32_t ref, float tnear)
+{
+  const uint2 e = make_uint2(ref, f_as_u(tnear));
+  if (k < s.lds_entries) s.lds[k * 64u] = e;
+  else s.spill[(size_t)(k - s.lds_entries) * 64u] = e;
+}
+
+PT_DEV uint2 stack4_read(const Stack4& s, uint32_t k)
+{
+  if (k < s.lds_entries) return s.lds[k * 64u];
+  return s.spill[(size_t)(k - s.lds_entries) * 64u];
+}
+
+// Next reference whose entry distance does not lie beyond the best hit (PT_NONE: the stack is empty — walk over).
+PT_DEV uint32_t stack4_pop(const Stack4& s, uint32_t& sp, float best_t)
+{
+  while (sp > 0u) {
+    --sp;
+    const uint2 e = stack4_read(s, sp);
+    if (u_as_f(e.y) <= best_t) return e.x;
+  }
+  return PT_NONE;
+}
+
+// Visits interior node `cur`: tests its four child boxes, stacks the hit ones, returns the nearest (or pops).
+template <bool STATS>
+PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk& w, uint32_t cur, uint32_t& sp)
+{
+  float4 lx, ly, lz, hx, hy, hz;
+  uint4 refs, ord;
+  if (cur < stk.top_n) {
+    const float4* q = stk.top + cur * 8u;
+    lx = q[0]; ly = q[1]; lz = q[2]; hx = q[3]; hy = q[4]; hz = q[5];
+    refs = *reinterpret_cast<const uint4*>(q + 6);
+    ord = *reinterpret_cast<const uint4*>(q + 7);
+  } else {
+    const float4* q = nodes4 + (size_t)cur * 8u;
+    lx = q[0]; ly = q[1]; lz = q[2]; hx = q[3]; hy = q[4]; hz = q[5];
+    refs = *reinterpret_cast<const uint4*>(q + 6);
+    ord = *reinterpret_cast<const uint4*>(q + 7);
+#ifdef PT_EXPERIMENT_DUP_LOADS   /* scratch experiment: how much do extra tag lookups of an L1-resident line cost? */
+    {
+      const volatile float4* v = reinterpret_cast<const volatile float4*>(q);
+      float acc = 0.f;
+      for (int i = 0; i < PT_EXPERIMENT_DUP_LOADS; ++i) { const float4 t = const_cast<const float4&>(v[i & 7]); acc += t.x; }
+      if (acc == 1.2345e-30f) lx.x = acc;
+    }
+#endif
+  }
+  float tn[4];
+  uint32_t hit = 0;
+#define PT_CHILD(c, X)                                                                                                   \
+  {                                                                                                                      \
+    const float t0x = __builtin_fmaf(lx.X, w.inv.x, w.noi.x), t1x = __builtin_fmaf(hx.X, w.inv.x, w.noi.x);               \
+    const float t0y = __builtin_fmaf(ly.X, w.inv.y, w.noi.y), t1y = __builtin_fmaf(hy.X, w.inv.y, w.noi.y);               \
+    const float t0z = __builtin_fmaf(lz.X, w.inv.z, w.noi.z), t1z = __builtin_fmaf(hz.X, w.inv.z, w.noi.z);               \
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),            \
+                                        __builtin_fminf(t0z, t1z));                                                      \
+    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),             \
+                                       __builtin_fmaxf(t0z, t1z));                                                       \
+    tn[c] = __builtin_fmaxf(tnear, 0.0f);                                                                                \
+    if (tn[c] <= __builtin_fminf(tfar, w.best.t)) hit |= 1u << c;                                                        \
+  }
+  PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w)
+#undef PT_CHILD
+  if (hit == 0u) return stack4_pop(stk, sp, w.best.t);
+  // halfword `oct` of q7: nibble c = the children this octant visits after child c
+  const uint32_t pair = (w.oct & 4u) ? ((w.oct & 2u) ? ord.w : ord.z) : ((w.oct & 2u) ? ord.y : ord.x);
+  const uint32_t order = (w.oct & 1u) ? (pair >> 16) : (pair & 0xFFFFu);
+  const uint32_t nhit = (uint32_t)__builtin_popcount(hit);
+  const uint32_t ref[4] = { refs.x, refs.y, refs.z, refs.w };
+  uint32_t next = PT_NONE;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if ((hit >> c) & 1u) {
+      // rank = hit children farther than c: the farthest goes deepest, the nearest is visited next without a round trip
+      // through the stack
+      const uint32_t rank = (uint32_t)__builtin_popcount(hit & (order >> (4 * c)) & 0xFu);
+      if (rank + 1u == nhit) next = ref[c];
+      else stack4_write(stk, sp + rank, ref[c], tn[c]);
+    }
+  }
+  sp += nhit - 1u;
+  return next;
+}
+
+// One round of the wide walk for the lanes that call it (see traverse_round): cur == PT_NONE on return: finished.
+template <bool STATS>
+PT_DEV void traverse_round4(const float4* nodes4, const float4* tris, const Stack4& stk, f3 o, f3 d, Best& best, uint32_t& cur,
+                            uint32_t& sp, uint32_t round_min, uint32_t round_div, uint32_t walk_min, Counters& cnt)
+{
+  Walk w;
+  walk_init(w, o, d, 1u);
+  w.best = best;
+  const uint32_t n_start = (uint32_t)__popcll(__ballot(cur != PT_NONE));
+  uint32_t t_eff = (n_start + round_div - 1u) / round_div;
+  if (t_eff > round_min) t_eff = round_min;
+  if (t_eff < 1u) t_eff = 1u;
+  for (;;) {
+    // box phase: every lane that holds an interior node visits it; the phase ends when fewer than walk_min lanes do
+    for (;;) {
+      const bool interior = cur < PT_LEAF_BIT;
+      const uint32_t walkers = (uint32_t)__popcll(__ballot(interior));
+      if (walkers == 0u) break;
+      if (interior) {
+        if (STATS) {
+          cnt.nodes++;
+          if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) cnt.wave_node_iters++;
+        }
+        cur = walk4_visit<STATS>(nodes4, stk, w, cur, sp);
+      }
+      if (walkers < walk_min) break;
+    }
+    // leaf phase: the leaf's triangle records come from L2 — fetch them all before the first test (one round trip
+    // instead of one per triangle; leaves hold at most three, longer ones finish in the plain loop)
+    if (cur != PT_NONE && (cur & PT_LEAF_BIT)) {
+      const uint32_t first = cur & 0xFFFFFFu, count = (cur >> 24) & 0x7Fu;
+      const float4* t = tris + (size_t)first * 3u;
+      float4 r[9];
+#pragma unroll
+      for (uint32_t k = 0; k < 3u; ++k)
+        if (k < count) { r[3 * k] = t[3 * k]; r[3 * k + 1] = t[3 * k + 1]; r[3 * k + 2] = t[3 * k + 2]; }
+#pragma unroll
+      for (uint32_t k = 0; k < 3u; ++k)
+        if (k < count) {
+          if (STATS) {
+            const unsigned long long act = __ballot(1);
+            if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) ++cnt.wave_tri_iters;
+          }
+          mt_test<false>(r[3 * k], r[3 * k + 1], r[3 * k + 2], w.o, w.d, w.best);
+        }
+      if (STATS) cnt.tris += count < 3u ? count : 3u;
+      if (count > 3u) walk_leaf<STATS>(tris, w, first + 3u, count - 3u, cnt.tris, cnt.wave_tri_iters);
+      cur = stack4_pop(stk, sp, w.best.t);
+    }
+    if ((uint32_t)__popcll(__ballot(cur != PT_NONE)) < t_eff) break;
+  }
+  best = w.best;
+}
+
 template <bool LDS_RESIDENT, bool STATS>
-__global__ void __launch_bounds__(PT_RS_THREADS, PT_RS_WAVES_PER_EU) pt_megakernel_restart(const KParams p)
+__global__ void __launch_bounds__(PT_RS_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_EU : PT_RS4_WAVES_PER_EU) pt_megakernel_restart(const KParams p)
 {
   extern __shared__ float4 s_mem[];
   const float4* s_nodes;
   const float4* s_tris;
   stage_scene<2, LDS_RESIDENT, LDS_RESIDENT && !STATS && PT_ASM_WALK>(p, s_mem, s_nodes, s_tris);
+  // scenes that do not fit in LDS are walked in the four-wide form; LDS then holds the waves' stacks
+  constexpr bool WIDE = !LDS_RESIDENT;
 
   const uint32_t lane = threadIdx.x & 63u;
-  float4* slab = p.pool + (size_t)(blockIdx.x * (PT_RS_THREADS / 64u) + (threadIdx.x >> 6)) * 192u;
+  const uint32_t gwave = blockIdx.x * (PT_RS_THREADS / 64u) + (threadIdx.x >> 6);
+  float4* slab = p.pool + (size_t)gwave * 192u;
+  Stack4 stk;
+  stk.top = s_mem;
+  stk.top_n = WIDE ? p.treelet_nodes : 0u;
+  if (WIDE) {
+    stage_to_lds(s_mem, p.nodes4, p.treelet_nodes * 8u);
+    __syncthreads();
+  }
+  stk.lds = reinterpret_cast<uint2*>(s_mem + (size_t)p.treelet_nodes * 8u) + (size_t)(threadIdx.x >> 6) * p.stack_lds_entries * 64u + lane;
+  stk.spill = p.stack_spill + (size_t)gwave * p.stack_spill_entries * 64u + lane;
+  stk.lds_entries = p.stack_lds_entries;
+  uint32_t cur = PT_NONE, sp = 0;   // wide walk: reference to process next, entries on the stack
   Counters cnt = {};
   uint32_t samples = 0;
 
@@ -1107,10 +1289,17 @@ __global__ void __launch_bounds__(PT_RS_THREADS, PT_RS_WAVES_PER_EU) pt_megakern
         r1 = path_pre(p, st);
         best.t = PT_MAX_DIST; best.u = 0.f; best.v = 0.f; best.idx = PT_END;
         node = p.n_nodes ? 0u : PT_END;
+        cur = p.n_nodes4 ? 0u : PT_NONE;
+        sp = 0u;
         walking = true;
         if (STATS) cnt.rays++;
       }
-      traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.walk_min, cnt);
+      if (WIDE) {
+        traverse_round4<STATS>(p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, cnt);
+        node = cur == PT_NONE ? PT_END : 0u;
+      } else {
+        traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.walk_min, cnt);
+      }
       if (STATS) {   // fetch_events: rounds of this wave; fetch_rays: walks that completed in them
         if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) cnt.fetch_events++;
         if (node == PT_END) cnt.fetch_rays++;
@@ -1530,6 +1719,34 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel4(const KParams p)
   *reinterpret_cast<uint4*>(p.surface + (size_t)(y - p.surf_row0) * p.width + x0) = make_uint4(px[0], px[1], px[2], px[3]);
 }
 
+// The same query through the four-wide walk: one wave per block, the stack entirely in (dynamic) LDS.
+__global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(const KParams p, const float* rays, uint32_t n, int4* out)
+{
+  extern __shared__ float4 s_mem[];
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  const bool live = i < n;
+  Stack4 stk;
+  stk.lds = reinterpret_cast<uint2*>(s_mem) + threadIdx.x;
+  stk.spill = p.stack_spill;   // never reached: the host sizes the LDS part for the whole stack
+  stk.lds_entries = p.stack_lds_entries;
+  stk.top = s_mem;
+  stk.top_n = 0u;
+  f3 d = mk3(0.f, 0.f, 1.f), o = mk3(0.f);
+  if (live) { d = mk3(rays[i * 6 + 0], rays[i * 6 + 1], rays[i * 6 + 2]); o = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]); }
+  Counters cnt = {};
+  Best best;
+  best.t = PT_MAX_DIST; best.u = best.v = 0.f; best.idx = PT_END;
+  uint32_t cur = (live && p.n_nodes4) ? 0u : PT_NONE, sp = 0u;
+  if (live) traverse_round4<false>(p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, cnt);
+  if (!live) return;
+  Nearest nr;
+  nr.t = best.t; nr.u = best.u; nr.v = best.v; nr.idx = best.idx;
+  nr = nearest_lights(p, o, d, nr);
+  const int kind = nr.idx == PT_END ? 0 : ((nr.idx & PT_LIGHT) ? 2 : 1);
+  const int index = kind == 0 ? -1 : (int)(nr.idx & ~PT_LIGHT);
+  out[i] = make_int4(kind, index, (int)f_as_u(nr.t), 0);
+}
+
 // Nearest-hit query on explicit rays (tests: BVH vs brute force on the device).
 template <int KIND>
 __global__ void __launch_bounds__(256) pt_trace_rays_kernel(const KParams p, const float* rays, uint32_t n, int4* out)
@@ -1628,10 +1845,12 @@ static const void* restart_select(bool lds_resident, bool stats)
 }
 
 uint32_t restart_threads() { return PT_RS_THREADS; }
+// wide walk: resident workgroups per CU the launch bounds aim for (their LDS share holds the waves' stacks)
+uint32_t restart_wide_blocks_per_cu() { return (PT_RS4_WAVES_PER_EU * 256u) / PT_RS_THREADS; }
 
+// lds_bytes: the staged scene when lds_resident, else the stacks of the wide walk
 hipError_t restart_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out)
 {
-  if (!lds_resident) lds_bytes = 0;
   const void* fn = restart_select(lds_resident, false);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1644,7 +1863,6 @@ hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t
                                      uint32_t n_blocks, hipStream_t stream)
 {
   if (p.n_tiles == 0 || n_blocks == 0) return hipSuccess;
-  if (!lds_resident) lds_bytes = 0;
   const void* fn = restart_select(lds_resident, stats);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1764,6 +1982,7 @@ hipError_t resolve_kernels()
     reinterpret_cast<const void*>(pt_megakernel<2, false, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_resolve_kernel), reinterpret_cast<const void*>(pt_resolve_kernel4),
     reinterpret_cast<const void*>(pt_trace_rays_kernel<1>), reinterpret_cast<const void*>(pt_trace_rays_kernel<2>),
+    reinterpret_cast<const void*>(pt_trace_rays_wide_kernel),
   };
   for (const void* fn : fns) {
     hipFuncAttributes attr;
@@ -1777,6 +1996,15 @@ hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, 
                              hipStream_t stream)
 {
   if (n == 0) return hipSuccess;
+  if (kind == 3) {   // four-wide walk; p.stack_lds_entries covers the whole stack (3 x depth of the wide tree)
+    const size_t lds = (size_t)p.stack_lds_entries * 64u * sizeof(uint2);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_rays_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(pt_trace_rays_wide_kernel, dim3((n + 63u) / 64u), dim3(64), lds, stream, p, rays_dev, n, out_dev);
+    return hipGetLastError();
+  }
   dim3 grid((n + 255u) / 256u);
   if (kind == 1) hipLaunchKernelGGL(pt_trace_rays_kernel<1>, grid, dim3(256), 0, stream, p, rays_dev, n, out_dev);
   else hipLaunchKernelGGL(pt_trace_rays_kernel<2>, grid, dim3(256), 0, stream, p, rays_dev, n, out_dev);

@@ -27,6 +27,7 @@ namespace {
 
 struct DeviceScene {
   float4* nodes = nullptr;
+  float4* nodes4 = nullptr;   // the four-wide form of the same tree (8 float4 per node)
   float4* tris_bvh = nullptr;
   float4* tris_brute = nullptr;
   float4* shade = nullptr;
@@ -36,6 +37,7 @@ struct DeviceScene {
   float* texels = nullptr;
   uint32_t n_faces = 0, n_lights = 0, n_nodes = 0, n_materials = 0, n_textures = 0;
   uint32_t n_bvh_tris = 0; // triangle records behind the BVH leaves (>= n_faces with split references)
+  uint32_t n_nodes4 = 0, depth4 = 0;
   float extent = 0.0f;       // largest |coordinate| of the scene (bvh_builder.cpp)
   float margin_floor = 0.0f; // smallest inflation of any box face: what the slab test's rounding error must stay below
   ptamd_scene_info info{};
@@ -74,6 +76,8 @@ struct ptamd_context {
   // measured (scripts/gpu_r2_sweep.sh, 1080p x 4 spp x 4 bounces): round_min 16-32 and walk_min 4-6 are a flat optimum
   uint32_t round_min = 16, round_div = 4; // PTAMD_ROUND_MIN, PTAMD_ROUND_DIV
   uint32_t walk_min = 5;                  // restart kernel: a box phase ends once fewer lanes than this still walk (PTAMD_WALK_MIN)
+  uint32_t treelet_nodes = 341;           // wide walk: nodes of the top of the tree staged in LDS (PTAMD_TREELET)
+  uint32_t walk_min4 = 16;                // the same threshold for the four-wide walk (PTAMD_WALK_MIN4; 1/4/8/16/24: 813/902/960/994/971 Msamples/s)
   uint32_t tiles_per_ticket = 1;
 };
 
@@ -120,7 +124,7 @@ int upload(T*& dst, const void* src, size_t bytes)
 
 void free_scene(DeviceScene& s)
 {
-  void* ptrs[] = { s.nodes, s.tris_bvh, s.tris_brute, s.shade, s.materials, s.lights, s.textures, s.texels };
+  void* ptrs[] = { s.nodes, s.nodes4, s.tris_bvh, s.tris_brute, s.shade, s.materials, s.lights, s.textures, s.texels };
   for (void* q : ptrs) (void)hipFree(q);
   s = DeviceScene();
 }
@@ -172,6 +176,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   p.materials = s.materials; p.lights = s.lights; p.textures = s.textures; p.texels = s.texels;
   p.cubemap = cm.faces; p.cubemap_size = cm.size;
   p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
+  p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4;
 
   // generateRay's pixel-invariant part (intersection.cuh:79-89)
   const ptamd_camera& cam = l->camera;
@@ -264,12 +269,30 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       set_error("ptamd_raytrace: rows x width x frame_count too large for one launch (split the batch)");
       return PTAMD_ERR_LIMIT;
     }
+    // restart kernel on a scene that does not fit in LDS: the four-wide walk.  Its per-lane stack needs at most
+    // 3 x (depth of the wide tree) entries of 8 bytes; as many as fit the workgroup's LDS share live in LDS
+    // ([entry][lane], 512 bytes per entry and wave), the rest in a global slab.
+    size_t launch_lds = lds;
+    if (restart && !resident) {
+      const uint32_t need = 3u * s.depth4 + 1u;
+      const uint32_t waves = restart_threads() / 64u;
+      const uint32_t share = 160u * 1024u / restart_wide_blocks_per_cu() - 256u;   // LDS bytes of one resident workgroup
+      // the top of the tree (breadth-first numbering: nodes 0..340 are its first five levels when full) goes to LDS too
+      uint32_t treelet = ctx->treelet_nodes < s.n_nodes4 ? ctx->treelet_nodes : s.n_nodes4;
+      if (treelet * 128u + waves * 512u * 4u > share) treelet = (share - waves * 512u * 4u) / 128u;   // keep >= 4 stack entries
+      uint32_t fit = (share - treelet * 128u) / (waves * 512u);
+      if (const char* ev = std::getenv("PTAMD_STACK_LDS")) { int v = std::atoi(ev); if (v >= 1 && (uint32_t)v <= fit) fit = (uint32_t)v; }   // tuning knob
+      p.treelet_nodes = treelet;
+      p.stack_lds_entries = need < fit ? need : fit;
+      p.stack_spill_entries = need - p.stack_lds_entries;
+      launch_lds = (size_t)treelet * 128u + (size_t)p.stack_lds_entries * waves * 512u;
+    }
     ptamd_context::Occupancy& occ = ctx->occupancy[split ? 2 : (restart ? 3 : 0)];
-    const size_t occ_key = resident ? lds : 0;
+    const size_t occ_key = resident ? lds : (restart ? launch_lds + 1u : 0);
     if (occ.blocks_per_cu < 0 || occ.lds != occ_key) {
       int q = -1;
       e = split ? split_blocks_per_cu(resident, lds, &q)
-                : (restart ? restart_blocks_per_cu(resident, lds, &q) : persistent_blocks_per_cu(resident, lds, &q));
+                : (restart ? restart_blocks_per_cu(resident, launch_lds, &q) : persistent_blocks_per_cu(resident, lds, &q));
       if (e != hipSuccess || q < 1) { occ.blocks_per_cu = -1; return hip_fail("occupancy query of the persistent kernel", e); }
       occ.blocks_per_cu = q; occ.lds = occ_key;
     }
@@ -296,7 +319,8 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     if (parks) {
       const size_t sample_bytes = ((size_t)count * rows * l->width * 3u * sizeof(float) + 255u) & ~(size_t)255u;
       const size_t pool_bytes = restart ? (size_t)n_blocks * waves_per_block * 192u * sizeof(float4) : 0u;
-      const size_t need = sample_bytes + pool_bytes;
+      const size_t spill_bytes = (size_t)n_blocks * waves_per_block * p.stack_spill_entries * 512u;
+      const size_t need = sample_bytes + pool_bytes + spill_bytes + 16u;
       ptamd_context::SampleScratch* sc = nullptr;
       for (auto& c : ctx->sample_scratch) if (c.stream == l->stream) sc = &c;
       if (!sc) {
@@ -320,10 +344,12 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       }
       p.samples_out = sc->buf;
       p.pool = reinterpret_cast<float4*>(reinterpret_cast<char*>(sc->buf) + sample_bytes);
+      p.stack_spill = reinterpret_cast<uint2*>(reinterpret_cast<char*>(sc->buf) + sample_bytes + pool_bytes);
     }
     p.round_min = ctx->round_min;
     p.round_div = ctx->round_div;
     p.walk_min = ctx->walk_min;
+    p.walk_min4 = ctx->walk_min4;
     p.tiles_per_ticket = tiles_per_ticket;
     // tickets 0..n_waves-1 are taken statically by the waves; the shared counter hands out the rest
     const uint32_t slot = ctx->ticket_next++ % kTicketRing;
@@ -335,7 +361,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_heads), 0, 8u * PT_HEAD_STRIDE, stream));
     }
     if (split) { p.tiles_per_ticket = 1; e = launch_megakernel_split(p, resident, lds, stats, n_blocks, stream); }
-    else if (restart) e = launch_megakernel_restart(p, resident, lds, stats, n_blocks, stream);
+    else if (restart) e = launch_megakernel_restart(p, resident, launch_lds, stats, n_blocks, stream);
     else e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
     if (e == hipSuccess && parks) e = launch_resolve(p, stream);
   } else {
@@ -403,6 +429,14 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   if (const char* e = std::getenv("PTAMD_WALK_MIN")) { // tuning knob
     int v = std::atoi(e);
     ctx->walk_min = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+  }
+  if (const char* e = std::getenv("PTAMD_WALK_MIN4")) { // tuning knob
+    int v = std::atoi(e);
+    ctx->walk_min4 = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+  }
+  if (const char* e = std::getenv("PTAMD_TREELET")) { // tuning knob
+    int v = std::atoi(e);
+    ctx->treelet_nodes = (uint32_t)(v < 0 ? 0 : (v > 1024 ? 1024 : v));
   }
   if (const char* e = std::getenv("PTAMD_ROUND_DIV")) { // tuning knob
     int v = std::atoi(e);
@@ -507,8 +541,10 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   DeviceScene d;
   d.n_faces = sc->n_faces; d.n_lights = sc->n_lights; d.n_nodes = bvh.n_nodes; d.n_bvh_tris = bvh.n_tris;
   d.extent = bvh.extent; d.margin_floor = bvh.margin_floor;
+  d.n_nodes4 = bvh.n_nodes4; d.depth4 = bvh.depth4;
   d.n_materials = sc->n_materials; d.n_textures = sc->n_textures;
   if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
+      (rc = upload(d.nodes4, bvh.nodes4.data(), bvh.nodes4.size() * 4)) ||
       (rc = upload(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4)) ||
       (rc = upload(d.tris_brute, brute.data(), brute.size() * 4)) ||
       (rc = upload(d.shade, shade.data(), shade.size() * 4)) ||
@@ -522,6 +558,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   d.info.n_faces = sc->n_faces; d.info.n_lights = sc->n_lights; d.info.n_nodes = bvh.n_nodes;
   d.info.n_leaves = bvh.n_leaves; d.info.max_leaf_size = bvh.max_leaf; d.info.depth = bvh.depth;
   d.info.node_bytes = 64; d.info.tri_bytes = 48;
+  d.info.n_nodes4 = bvh.n_nodes4; d.info.depth4 = bvh.depth4;
   d.info.lds_bytes_bvh = bvh.n_nodes * 64u + bvh.n_tris * 48u;
   d.info.lds_bytes_brute = sc->n_faces * 48u;
   ctx->scenes.push_back(d);
@@ -623,7 +660,8 @@ int ptamd_scene_info_get(ptamd_context* ctx, uint32_t scene_id, ptamd_scene_info
 int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, const float* rays_host, uint32_t n,
                      int32_t* out_host)
 {
-  if (!ctx || scene_id >= ctx->scenes.size() || (n && (!rays_host || !out_host)) || kernel > PTAMD_KERNEL_BVH) {
+  if (!ctx || scene_id >= ctx->scenes.size() || (n && (!rays_host || !out_host)) ||
+      (kernel > PTAMD_KERNEL_BVH && kernel != PTAMD_KERNEL_BVH_RESTART)) {
     set_error("ptamd_trace_rays: bad argument");
     return PTAMD_ERR_ARG;
   }
@@ -634,6 +672,8 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   std::memset(&p, 0, sizeof p);
   p.nodes = s.nodes; p.tris_bvh = s.tris_bvh; p.tris_brute = s.tris_brute; p.lights = s.lights;
   p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
+  p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4;
+  p.stack_lds_entries = 3u * s.depth4 + 1u;   // PTAMD_KERNEL_BVH_RESTART: the four-wide walk, whole stack in LDS
   float* d_rays = nullptr;
   int4* d_out = nullptr;
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));
@@ -641,7 +681,7 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   if (e != hipSuccess) { (void)hipFree(d_rays); return hip_fail("hipMalloc", e); }
   int rc = PTAMD_OK;
   if ((e = hipMemcpy(d_rays, rays_host, (size_t)n * 24, hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = launch_trace_rays(p, kernel == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2, d_rays, n, d_out, nullptr)) != hipSuccess ||
+      (e = launch_trace_rays(p, kernel == PTAMD_KERNEL_BRUTE_FORCE ? 1 : (kernel == PTAMD_KERNEL_BVH_RESTART ? 3 : 2), d_rays, n, d_out, nullptr)) != hipSuccess ||
       (e = hipDeviceSynchronize()) != hipSuccess ||
       (e = hipMemcpy(out_host, d_out, (size_t)n * 16, hipMemcpyDeviceToHost)) != hipSuccess)
     rc = hip_fail("ptamd_trace_rays", e);

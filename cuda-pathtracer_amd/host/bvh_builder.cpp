@@ -357,6 +357,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   out.extent = extent;
   out.margin_floor = margin + origin_margin;
   uint32_t tri_cursor = 0;
+  std::vector<uint32_t> leaf_info(b.nodes.size(), 0u);   // build-node id -> first_tri | count << 24 (leaves only)
   for (uint32_t k = 0; k < n_nodes; ++k) {
     const BuildNode& bn = b.nodes[order[k]];
     float* q = &out.nodes[(size_t)k * 16];
@@ -374,6 +375,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
       std::sort(ids.begin(), ids.end());
       ids.erase(std::unique(ids.begin(), ids.end()), ids.end()); // two references of one face in one leaf
       info = tri_cursor | ((uint32_t)ids.size() << 24);
+      leaf_info[order[k]] = info;
       out.max_leaf = std::max(out.max_leaf, (uint32_t)ids.size());
       for (uint32_t fi : ids) {
         const ptamd_face& f = faces[fi];
@@ -399,7 +401,191 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   }
   out.tris.resize((size_t)tri_cursor * 12);
   out.n_tris = tri_cursor;
+
+  // ---- the same tree, collapsed to four children per node (layout: ptamd_internal.h).  A node's children start as the
+  // two children of a binary node; the interior child with the largest box is replaced by its own two children until
+  // there are four (or only leaves are left).  Leaves keep their triangle ranges in `tris`.
+  {
+    struct Wide { int child[4]; int n; };
+    std::vector<Wide> wide;
+    std::vector<int> wide_root;       // build-node id each wide node was made from
+    std::vector<uint32_t> wide_depth;
+    wide_root.push_back(0);
+    wide_depth.push_back(1);
+    for (size_t w = 0; w < wide_root.size(); ++w) {      // breadth-first: the top of the tree is contiguous
+      Wide wn;
+      wn.n = 0;
+      const BuildNode& root = b.nodes[(size_t)wide_root[w]];
+      if (root.left < 0) { wn.child[wn.n++] = wide_root[w]; }          // a one-leaf tree: the root node holds that leaf
+      else { wn.child[wn.n++] = root.left; wn.child[wn.n++] = root.right; }
+      while (wn.n < 4) {
+        int pick = -1;
+        float area = -1.0f;
+        for (int i = 0; i < wn.n; ++i) {
+          const BuildNode& c = b.nodes[(size_t)wn.child[i]];
+          if (c.left >= 0 && c.box.half_area() > area) { area = c.box.half_area(); pick = i; }
+        }
+        if (pick < 0) break;
+        const BuildNode& c = b.nodes[(size_t)wn.child[pick]];
+        wn.child[pick] = c.left;
+        wn.child[wn.n++] = c.right;
+      }
+      for (int i = wn.n; i < 4; ++i) wn.child[i] = -1;
+      wide.push_back(wn);
+      out.depth4 = std::max(out.depth4, wide_depth[w]);
+      for (int i = 0; i < wn.n; ++i)
+        if (b.nodes[(size_t)wn.child[i]].left >= 0) {
+          // interior child: becomes a wide node of its own; remember where (negative marker resolved below)
+          wide_root.push_back(wn.child[i]);
+          wide_depth.push_back(wide_depth[w] + 1);
+        }
+    }
+    // wide node index of every build node that became one (in push order)
+    std::vector<int> wide_of(b.nodes.size(), -1);
+    for (size_t w = 0; w < wide_root.size(); ++w) wide_of[(size_t)wide_root[w]] = (int)w;
+    out.n_nodes4 = (uint32_t)wide.size();
+    out.nodes4.assign((size_t)out.n_nodes4 * 32, 0.0f);
+    for (size_t w = 0; w < wide.size(); ++w) {
+      float* q = &out.nodes4[w * 32];
+      float key[4][8];
+      for (int c = 0; c < 4; ++c) {
+        if (wide[w].child[c] < 0) {
+          // empty slot: a point box far beyond MAX_DIST (no ray reaches it: its slab distances are +-huge, never within
+          // [0, best <= 1e5]), reference 0xFFFFFFFF
+          for (int a = 0; a < 3; ++a) { q[a * 4 + c] = 3.0e38f; q[12 + a * 4 + c] = 3.0e38f; }
+          q[24 + c] = u2f(0xFFFFFFFFu);
+          continue;
+        }
+        const BuildNode& cn = b.nodes[(size_t)wide[w].child[c]];
+        for (int a = 0; a < 3; ++a) {
+          const float lo = cn.box.lo[a], hi = cn.box.hi[a];
+          q[a * 4 + c] = lo - (margin + origin_margin + std::fabs(lo) * 1e-6f);
+          q[12 + a * 4 + c] = hi + (margin + origin_margin + std::fabs(hi) * 1e-6f);
+        }
+        uint32_t ref;
+        if (cn.left < 0) {
+          const uint32_t info = leaf_info[(size_t)wide[w].child[c]];
+          ref = 0x80000000u | ((info >> 24) << 24) | (info & 0xFFFFFFu);   // leaf: count in bits 24..30, first triangle below
+        } else {
+          ref = (uint32_t)wide_of[(size_t)wide[w].child[c]];
+        }
+        q[24 + c] = u2f(ref);
+        // traversal order of octant o: children sorted by the centre of their box along (+-1, +-1, +-1)
+        for (int o = 0; o < 8; ++o) {
+          float k = 0.0f;
+          for (int a = 0; a < 3; ++a) {
+            const float ctr = 0.5f * cn.box.lo[a] + 0.5f * cn.box.hi[a];
+            k += ((o >> a) & 1) ? -ctr : ctr;
+          }
+          key[c][o] = k;
+        }
+      }
+      // halfword o of q[28..31]: nibble c = the children a ray of octant o visits AFTER child c (farther ones)
+      uint32_t words[4] = { 0, 0, 0, 0 };
+      for (int o = 0; o < 8; ++o) {
+        uint32_t half = 0;
+        for (int c = 0; c < 4; ++c) {
+          if (wide[w].child[c] < 0) continue;
+          uint32_t farther = 0;
+          for (int d = 0; d < 4; ++d) {
+            if (d == c || wide[w].child[d] < 0) continue;
+            if (key[d][o] > key[c][o] || (key[d][o] == key[c][o] && d > c)) farther |= 1u << d;
+          }
+          half |= farther << (4 * c);
+        }
+        words[o >> 1] |= half << (16 * (o & 1));
+      }
+      for (int i = 0; i < 4; ++i) q[28 + i] = u2f(words[i]);
+    }
+  }
   return PTAMD_OK;
+}
+
+// Mirror of the device's four-wide walk (csrc/pt_kernels.hip: walk4_*): a stack of (reference, entry distance); a node's
+// hit children are pushed farthest first in the node's order for the ray's octant; entries whose entry distance lies
+// beyond the best hit are dropped when popped.  Result contract as for the binary walk.
+void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
+                     uint64_t* tris_tested)
+{
+  const float MAX_DIST = 100000.0f;
+  float best_t = MAX_DIST, best_u = 0.f, best_v = 0.f;
+  uint32_t best_idx = 0xFFFFFFFFu;
+  const int oct = (dir[0] < 0.f ? 1 : 0) | (dir[1] < 0.f ? 2 : 0) | (dir[2] < 0.f ? 4 : 0);
+  float inv[3], noi[3];
+  for (int a = 0; a < 3; ++a) {
+    const float da = std::fabs(dir[a]) < 1e-30f ? std::copysign(1e-30f, dir[a]) : dir[a];
+    inv[a] = 1.0f / da;
+    noi[a] = -(origin[a] * inv[a]);
+  }
+  struct Entry { uint32_t ref; float tnear; };
+  std::vector<Entry> stack;
+  if (bvh.n_nodes4) stack.push_back({ 0u, 0.0f });
+  while (!stack.empty()) {
+    const Entry e = stack.back();
+    stack.pop_back();
+    if (!(e.tnear <= best_t)) continue;
+    if (e.ref & 0x80000000u) {
+      const uint32_t first = e.ref & 0xFFFFFFu, count = (e.ref >> 24) & 0x7Fu;
+      for (uint32_t k = 0; k < count; ++k) {
+        const float* t = &bvh.tris[(size_t)(first + k) * 12];
+        if (tris_tested) ++*tris_tested;
+        const float e1[3] = { t[0], t[1], t[2] }, e2[3] = { t[3], t[4], t[5] }, v0[3] = { t[6], t[7], t[8] };
+        const float p[3] = { dir[1] * e2[2] - dir[2] * e2[1], dir[2] * e2[0] - dir[0] * e2[2], dir[0] * e2[1] - dir[1] * e2[0] };
+        const float det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+        if (det < 1e-7f) continue;
+        const float inv_det = 1.0f / det;
+        const float tv[3] = { origin[0] - v0[0], origin[1] - v0[1], origin[2] - v0[2] };
+        const float u = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * inv_det;
+        if (u < 0 || u > 1) continue;
+        const float q[3] = { tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0] };
+        const float v = (dir[0] * q[0] + dir[1] * q[1] + dir[2] * q[2]) * inv_det;
+        if (v < 0 || u + v > 1) continue;
+        const float tt = (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]) * inv_det;
+        uint32_t idx;
+        std::memcpy(&idx, &t[9], 4);
+        if (tt > 0.0f && (tt < best_t || (tt == best_t && idx < best_idx && best_idx != 0xFFFFFFFFu))) {
+          best_t = tt; best_u = u; best_v = v; best_idx = idx;
+        }
+      }
+      continue;
+    }
+    const float* q = &bvh.nodes4[(size_t)e.ref * 32];
+    if (nodes_visited) {
+      ++*nodes_visited;
+      if (e.ref < 85u) ++nodes_visited[3];    // counters[3], [4] of ptamd_host_bvh4_trace: visits to the first 85 / 341 nodes
+      if (e.ref < 341u) ++nodes_visited[4];   // (breadth-first numbering: the top four / five levels of a full tree)
+    }
+    uint32_t hit = 0;
+    float tn[4];
+    for (int c = 0; c < 4; ++c) {
+      float tnear = -std::numeric_limits<float>::infinity(), tfar = std::numeric_limits<float>::infinity();
+      for (int a = 0; a < 3; ++a) {
+        const float t0 = std::fma(q[a * 4 + c], inv[a], noi[a]), t1 = std::fma(q[12 + a * 4 + c], inv[a], noi[a]);
+        tnear = std::max(tnear, std::min(t0, t1));
+        tfar = std::min(tfar, std::max(t0, t1));
+      }
+      tn[c] = std::max(tnear, 0.0f);
+      if (tn[c] <= std::min(tfar, best_t)) hit |= 1u << c;
+    }
+    uint32_t w;
+    std::memcpy(&w, &q[28 + (oct >> 1)], 4);
+    const uint32_t order = (w >> (16 * (oct & 1))) & 0xFFFFu;
+    // farthest first: a child goes below every child that is nearer than it
+    Entry pushed[4];
+    const int nhit = __builtin_popcount(hit);
+    for (int c = 0; c < 4; ++c) {
+      if (!((hit >> c) & 1u)) continue;
+      const int rank = __builtin_popcount(hit & ((order >> (4 * c)) & 0xFu));   // hit children farther than c
+      uint32_t ref;
+      std::memcpy(&ref, &q[24 + c], 4);
+      pushed[nhit - 1 - rank] = { ref, tn[c] };     // nearest last = on top
+    }
+    // pushed[] is in stack order: index 0 deepest (farthest)
+    for (int i = 0; i < nhit; ++i) stack.push_back(pushed[i]);
+  }
+  out.kind = best_idx == 0xFFFFFFFFu ? 0 : 1;
+  out.index = best_idx == 0xFFFFFFFFu ? -1 : (int32_t)best_idx;
+  out.t = best_t; out.u = best_u; out.v = best_v;
 }
 
 // Mirror of the device traversal (csrc/pt_kernels.hip: traverse_bvh); float ops in the same
@@ -480,6 +666,26 @@ void bvh_trace_host(const Bvh& bvh, const ptamd_face* faces, const float dir[3],
 }
 
 } // namespace ptamd
+
+extern "C" int ptamd_host_bvh4_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
+                                     int32_t* out, uint64_t* counters)
+{
+  if ((n_faces && !faces) || (n && (!rays || !out))) { ptamd::set_error("ptamd_host_bvh4_trace: null argument"); return PTAMD_ERR_ARG; }
+  ptamd::Bvh bvh;
+  int rc = ptamd::build_bvh(faces, n_faces, 1e-3f, 4, bvh);
+  if (rc != PTAMD_OK) return rc;
+  for (uint32_t i = 0; i < n; ++i) {
+    ptamd::HostHit h;
+    ptamd::bvh4_trace_host(bvh, rays + (size_t)i * 6, rays + (size_t)i * 6 + 3, h,
+                           counters ? &counters[0] : nullptr, counters ? &counters[1] : nullptr);
+    out[i * 4 + 0] = h.kind;
+    out[i * 4 + 1] = h.index;
+    std::memcpy(&out[i * 4 + 2], &h.t, 4);
+    out[i * 4 + 3] = 0;
+  }
+  if (counters) counters[2] = bvh.depth4;
+  return PTAMD_OK;
+}
 
 extern "C" int ptamd_host_bvh_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                                     int32_t* out, uint64_t* counters)

@@ -65,6 +65,14 @@ struct Bvh {
   std::vector<float> tris;       // 12 floats per triangle, leaf-major
   uint32_t n_nodes = 0, n_leaves = 0, max_leaf = 0, depth = 0;
   uint32_t n_tris = 0;           // triangle records (>= faces when references were split)
+  // The same tree with four children per node, for scenes walked from L2/HBM with a per-lane stack (one 128-byte line
+  // per node visit instead of one dependent 64-byte load per box test).  node record = 32 floats = 8 x float4:
+  //   q0..q2 = lo.x[4], lo.y[4], lo.z[4]     q3..q5 = hi.x[4], hi.y[4], hi.z[4]      (child boxes, one lane per child)
+  //   q6     = reference[4]: 0xFFFFFFFF empty | node index | 0x80000000 | count << 24 | first triangle (leaf)
+  //   q7     = 8 halfwords, one per ray octant: nibble c = the children that octant visits AFTER child c
+  // Nodes are numbered breadth-first (node 0 = root).  Leaves point into `tris`.
+  std::vector<float> nodes4;
+  uint32_t n_nodes4 = 0, depth4 = 0;
   float extent = 0.0f;           // largest |coordinate| of the scene
   float margin_floor = 0.0f;     // smallest inflation any box face received (absolute margin + extent * 2^-20)
 };
@@ -77,5 +85,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
 struct HostHit { int32_t kind; int32_t index; float t; float u, v; };
 void bvh_trace_host(const Bvh& bvh, const ptamd_face* faces, const float dir[3], const float origin[3],
                     HostHit& out, uint64_t* nodes_visited, uint64_t* tris_tested);
+void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
+                     uint64_t* tris_tested);
 
 } // namespace ptamd

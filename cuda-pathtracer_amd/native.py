@@ -83,7 +83,8 @@ class TraceStats(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("n_faces", "n_lights", "n_nodes", "n_leaves", "max_leaf_size", "depth",
-                                          "node_bytes", "tri_bytes", "lds_bytes_bvh", "lds_bytes_brute")]
+                                          "node_bytes", "tri_bytes", "lds_bytes_bvh", "lds_bytes_brute",
+                                          "n_nodes4", "depth4")]
 
 
 assert C.sizeof(Face) == 112 and C.sizeof(Material) == 16 and C.sizeof(Light) == 32 and C.sizeof(Camera) == 64
@@ -133,6 +134,8 @@ SIGNATURES = {
     "ptamd_trace_rays": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
                                    C.POINTER(C.c_int32)]),
     "ptamd_host_bvh_trace": (C.c_int, [C.POINTER(Face), C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "ptamd_host_bvh4_trace": (C.c_int, [C.POINTER(Face), C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "ptamd_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "ptamd_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),

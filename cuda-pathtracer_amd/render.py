@@ -169,6 +169,19 @@ def host_bvh_trace(scene: HostScene, rays: np.ndarray):
     return out, counters[0], counters[1]
 
 
+def host_bvh4_trace(scene: HostScene, rays: np.ndarray):
+    """Host mirror of the device's four-wide stack walk (test hook, no GPU): (int32[n,4], wide nodes visited,
+    triangles tested, depth of the wide tree)."""
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    out = np.zeros((len(rays), 4), dtype=np.int32)
+    counters = (C.c_uint64 * 5)(0, 0, 0, 0, 0)
+    N.check(N.load().ptamd_host_bvh4_trace(scene.faces.ctypes.data_as(C.POINTER(N.Face)), len(scene.faces),
+                                           rays.ctypes.data_as(C.POINTER(C.c_float)), len(rays),
+                                           out.ctypes.data_as(C.POINTER(C.c_int32)), counters))
+    host_bvh4_trace.top_visits = (counters[3], counters[4])   # visits to the first 85 / 341 nodes
+    return out, counters[0], counters[1], counters[2]
+
+
 def wang_hash(a: int) -> int:
     return N.load().ptamd_wang_hash(a & 0xFFFFFFFF)
 

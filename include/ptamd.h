@@ -271,6 +271,7 @@ int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_t
 typedef struct {
   uint32_t n_faces, n_lights, n_nodes, n_leaves, max_leaf_size, depth;
   uint32_t node_bytes, tri_bytes, lds_bytes_bvh, lds_bytes_brute;
+  uint32_t n_nodes4, depth4;   /* the four-wide form of the tree (128-byte nodes), walked when the scene does not fit in LDS */
 } ptamd_scene_info;
 int ptamd_scene_info_get(ptamd_context* ctx, uint32_t scene_id, ptamd_scene_info* out);
 
@@ -280,7 +281,9 @@ int ptamd_scene_info_get(ptamd_context* ctx, uint32_t scene_id, ptamd_scene_info
 int ptamd_device_error_count(ptamd_context* ctx, uint64_t* out);
 
 /* Nearest-hit query on explicit rays through the device traversal (tests: BVH vs brute
- * force equivalence).  rays: n * {dir.xyz, origin.xyz}; out: n * {kind, index, t bits, pad}. */
+ * force equivalence).  kernel: PTAMD_KERNEL_BRUTE_FORCE, PTAMD_KERNEL_BVH (binary walk) or
+ * PTAMD_KERNEL_BVH_RESTART (the four-wide stack walk).  rays: n * {dir.xyz, origin.xyz};
+ * out: n * {kind, index, t bits, pad}. */
 int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel,
                      const float* rays_host, uint32_t n, int32_t* out_host);
 
@@ -291,6 +294,13 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel,
  * counters (optional): [0] += nodes visited, [1] += triangles tested. */
 int ptamd_host_bvh_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                          int32_t* out, uint64_t* counters);
+
+/* The same for the four-wide form of the tree that scenes too big for LDS are walked in (per-lane stack, children
+ * visited in a per-octant order).  counters (optional, 5 words): [0] += wide nodes visited, [1] += triangles tested,
+ * [2] = depth of the wide tree, [3] / [4] += visits to the first 85 / 341 nodes (the part of the tree the device keeps
+ * in LDS is numbered first). */
+int ptamd_host_bvh4_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
+                          int32_t* out, uint64_t* counters);
 
 /* Plain device-memory helpers so that C/C++ hosts need not link HIP themselves. */
 int ptamd_device_alloc(ptamd_context* ctx, size_t bytes, void** out);

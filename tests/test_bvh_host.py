@@ -99,3 +99,65 @@ print(nodes, tris)
     env = dict(os.environ, PTAMD_BVH_SPLIT_ALPHA="0.01", PTAMD_BVH_SPLIT_BUDGET="200")
     split = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=env).stdout.split()
     assert base != split          # the knob did change the tree
+
+
+# ------------------------------------------------------------------ the four-wide form (scenes walked from L2)
+
+@pytest.mark.parametrize("name", ["indoor", "crate_land", "color_sample", "island", "sss_crate"])
+def test_wide_bvh_equals_brute_force_on_assets(P, O, name):
+    hs = P.HostScene.load(os.path.join(ASSETS, name + ".scene"))
+    rng = np.random.default_rng(17)
+    rays = random_rays(rng, 30000, extent=4.0)
+    f = hs.faces["vertices"][rng.integers(0, len(hs.faces), 15000)]
+    a, b = rng.uniform(size=(2, 15000, 1)).astype(np.float32)
+    flip = (a + b) > 1
+    a, b = np.where(flip, 1 - a, a), np.where(flip, 1 - b, b)
+    rays[:15000, 3:] = f[:, 0] + a * (f[:, 1] - f[:, 0]) + b * (f[:, 2] - f[:, 0]) + rays[:15000, :3] * np.float32(0.03)
+    want = O.intersect(lightless(O, P, hs), rays)
+    got, nodes, tris, depth = P.host_bvh4_trace(hs, rays)
+    np.testing.assert_array_equal(got, want)
+    got2, nodes2, tris2 = P.host_bvh_trace(hs, rays)
+    assert nodes < 0.6 * nodes2                     # a wide node visit replaces several box tests of the binary walk
+    assert tris < 0.2 * len(rays) * len(hs.faces) and 1 <= depth <= 16
+
+
+def test_wide_bvh_ties_degenerates_and_soup(P, O):
+    rng = np.random.default_rng(23)
+    base = random_soup(rng, 40)
+    hs = make_scene(P, np.concatenate([base, base[::-1], base]))          # coincident duplicates: lowest index wins
+    rays = random_rays(rng, 20000)
+    np.testing.assert_array_equal(P.host_bvh4_trace(hs, rays)[0], O.intersect(lightless(O, P, hs), rays))
+    soup = make_scene(P, random_soup(rng, 3000, extent=3.0, size=0.25))
+    rays = random_rays(rng, 20000)
+    got, nodes, tris, depth = P.host_bvh4_trace(soup, rays)
+    np.testing.assert_array_equal(got, O.intersect(lightless(O, P, soup), rays))
+    rays[:50, 0] = 0.0
+    rays[50:100, 1:3] = 0.0
+    empty = make_scene(P, np.zeros((0, 3, 3), np.float32))
+    got = P.host_bvh4_trace(empty, rays)[0]
+    assert (got[:, 0] == 0).all() and (got[:, 2].view(np.float32) == np.float32(100000.0)).all()
+    one = make_scene(P, np.float32([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]]))
+    np.testing.assert_array_equal(P.host_bvh4_trace(one, rays)[0], O.intersect(lightless(O, P, one), rays))
+    tris = random_soup(rng, 64)
+    tris[3] = tris[3][0]
+    tris[10, 1, 2] = np.nan
+    weird = make_scene(P, tris)
+    np.testing.assert_array_equal(P.host_bvh4_trace(weird, rays)[0], O.intersect(lightless(O, P, weird), rays))
+
+
+def test_wide_bvh_on_the_atrium(P, O, tmp_path):
+    """configs[3] asset: the wide walk == the binary walk on 20 000 rays (brute force over 264 832 faces is checked on the
+    GPU tests' oracle rows), depth of the wide tree bounded."""
+    from cuda_pathtracer_amd.synthetic import write_atrium
+    hs = P.HostScene.load(write_atrium(str(tmp_path)))
+    rng = np.random.default_rng(31)
+    rays = random_rays(rng, 20000, extent=5.0)
+    rays[:, 3] *= 2.0
+    rays[:, 4] = np.abs(rays[:, 4]) + 0.2
+    got4, nodes4, tris4, depth = P.host_bvh4_trace(hs, rays)
+    got2, nodes2, tris2 = P.host_bvh_trace(hs, rays)
+    np.testing.assert_array_equal(got4, got2)
+    assert (got4[:, 0] == 1).mean() > 0.5 and depth <= 24
+    want = O.intersect(lightless(O, P, hs), rays[:300])
+    np.testing.assert_array_equal(got4[:300], want)
+    print("atrium: wide nodes/ray %.1f, binary nodes/ray %.1f, depth %d" % (nodes4 / len(rays), nodes2 / len(rays), depth))

@@ -266,7 +266,7 @@ def test_trace_rays_device_equals_oracle(P, O, gpu_ctx):
         sid = gpu_ctx.upload_scene(hs)
         rays = random_rays(rng, 50000, extent=3.5)
         want = O.intersect(O.OracleScene.from_host_scene(hs, P.cubemap_from_color()), rays)
-        for k in (P.KERNEL_BVH, P.KERNEL_BRUTE_FORCE):
+        for k in (P.KERNEL_BVH, P.KERNEL_BRUTE_FORCE, P.KERNEL_BVH_RESTART):     # _RESTART: the four-wide stack walk
             np.testing.assert_array_equal(gpu_ctx.trace_rays(sid, rays, k), want)
         assert (want[:, 0] == 1).sum() > 5000
     soup = make_scene(P, random_soup(rng, 3000, extent=3.0, size=0.25))       # does not fit in LDS: global-memory variant
@@ -274,6 +274,23 @@ def test_trace_rays_device_equals_oracle(P, O, gpu_ctx):
     rays = random_rays(rng, 20000)
     want = O.intersect(O.OracleScene.from_host_scene(soup, P.cubemap_from_color()), rays)
     np.testing.assert_array_equal(gpu_ctx.trace_rays(sid, rays, P.KERNEL_BVH), want)
+    np.testing.assert_array_equal(gpu_ctx.trace_rays(sid, rays, P.KERNEL_BVH_RESTART), want)
+    assert gpu_ctx.scene_info(sid)["n_nodes4"] > 300 and gpu_ctx.scene_info(sid)["depth4"] >= 4
+
+
+def test_wide_walk_with_a_spilling_stack(P, O, gpu_ctx, monkeypatch):
+    """The four-wide walk keeps most of its per-lane stack in LDS and the rest in a global slab: with only two LDS entries
+    per lane (PTAMD_STACK_LDS) nearly every push beyond the second goes through the slab — same pixels."""
+    rng = np.random.default_rng(41)
+    hs = make_scene(P, random_soup(rng, 2500, extent=2.5, size=0.3), lights=[((0.0, 3.0, 1.0), (1, 1, 1), 6.0, 0.7)])
+    cube = synthetic_cubemap(rng, 4)
+    ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 96, 64, spp=2, bounces=4)
+    monkeypatch.setenv("PTAMD_STACK_LDS", "2")
+    acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 96, 64, 2, 4, P.KERNEL_BVH_RESTART)
+    assert_same(acc, rgba, *ref, "wide walk, stack mostly in the global slab")
+    monkeypatch.delenv("PTAMD_STACK_LDS")
+    acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 96, 64, 2, 4, P.KERNEL_BVH_RESTART)
+    assert_same(acc, rgba, *ref, "wide walk, stack in LDS")
 
 
 def test_large_scene_uses_global_memory_variant(P, O, gpu_ctx):
