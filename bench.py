@@ -80,6 +80,13 @@ def parse_args(argv=None):
     ap.add_argument("--rows", default=None, metavar="Y0:Y1",
                     help="N = 1 only: render just surface rows [Y0, Y1) of the frame (one rank's band of a multi-GPU split, "
                          "scripts/band_proxy.py); `value` then counts the band's samples")
+    ap.add_argument("--interleave", type=int, default=None, metavar="ROWS",
+                    help="N > 1: ranks own interleaved bands of ROWS rows (band j -> rank j %% N) instead of one contiguous band "
+                         "each; 0 = contiguous.  Default: 8 on several GPUs (contiguous eighths of the headline frame differ "
+                         "by 13 %% in cost, 8-row interleaved bands by 0.7 %%: profiles/r02_band_proxy_*.json)")
+    ap.add_argument("--as-rank", default=None, metavar="R/N",
+                    help="one GPU only: render what rank R of an N-GPU job renders (its contiguous band, or its interleaved "
+                         "bands with --interleave ROWS): the single-GPU proxy of scripts/band_proxy.py")
     ap.add_argument("--no-extra", action="store_true",
                     help="headline only: skip value_unpipelined / value_sequential / other_configs (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,7 +184,8 @@ class Workload:
     """A frame configuration on this rank: scene uploaded once, `n_slots` frames in flight (buffers + stream each)."""
 
     def __init__(self, P, torch, dist, hs, cube, W, H, spp, B, kernel_name, n_slots, share, batched, local_rank,
-                 world=1, rank=0, gather=False, rows=None):
+                 world=1, rank=0, gather=False, rows=None, interleave=None):
+        """interleave = (ranks, rank, band_rows): this rank owns interleaved bands instead of rows [y0, y1)."""
         self.P, self.torch, self.dist = P, torch, dist
         self.W, self.H, self.spp, self.B = W, H, spp, B
         self.world, self.rank = world, rank
@@ -188,6 +196,8 @@ class Workload:
         self.hs = hs
         self.dev = torch.device("cuda", local_rank)
         self.y0, self.y1 = P.row_bands(H, world)[rank] if rows is None else rows
+        self.interleave = interleave
+        self.my_rows = self.y1 - self.y0 if interleave is None else P.interleaved_rows(H, *interleave)
         self.ctx = P.Context(local_rank)
         self.ctx.setup_function_tables()
         self.sid = self.ctx.upload_scene(hs)
@@ -196,9 +206,14 @@ class Workload:
         self.slots = []
         for i in range(n_slots):
             fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(self.y0, self.y1),
-                                 band_local=True, machine_share=n_slots if (share and n_slots > 1) else 0)
-            # (a --rows band is gathered as if it were the whole frame: same message size as the rank's real gather share)
-            bg = P.BandGather(H if rows is None else self.y1 - self.y0, W, world, rank, self.dev) if gather else None
+                                 band_local=True, machine_share=n_slots if (share and n_slots > 1) else 0, interleave=interleave)
+            # (a proxy band is gathered as if it were the whole frame: same message size as the rank's real gather share)
+            if not gather:
+                bg = None
+            elif world == 1:
+                bg = P.BandGather(self.my_rows, W, 1, 0, self.dev)
+            else:
+                bg = P.BandGather(H, W, world, rank, self.dev, interleave=interleave[2] if interleave is not None else 0)
             st = torch.cuda.current_stream() if n_slots == 1 else torch.cuda.Stream(device=self.dev)
             self.slots.append((fr, bg, st))
         self.counter = 0
@@ -253,11 +268,11 @@ class Workload:
         stats = {k: 0 for k in ("rays", "nodes_visited", "tris_tested", "mesh_hits", "nmap_hits", "samples",
                                 "wave_node_iters", "idle_unstarted", "idle_finished", "idle_parked")}
         scratch = P.FrameRenderer(self.ctx, self.sid, self.cid, self.hs.camera_struct(), self.W, self.H,
-                                  rows=(self.y0, self.y1), band_local=True)
+                                  rows=(self.y0, self.y1), band_local=True, interleave=self.interleave)
         for k in range(1, self.spp + 1):
             l = self.ctx.make_launch(scratch.surface, scratch.accum, self.sid, self.cid, self.hs.camera_struct(), self.W,
-                                     self.H, frame_nb=k, bounces=self.B, rows=(self.y0, self.y1), kernel=self.kernel,
-                                     band_local_buffers=True)
+                                     self.H, frame_nb=k, bounces=self.B, rows=scratch.rows, kernel=self.kernel,
+                                     band_local_buffers=True, interleave=self.interleave)
             s = self.ctx.raytrace_stats(l)
             for key in stats:
                 stats[key] += s[key]
@@ -330,30 +345,43 @@ def main():
     gather = world > 1 or force_gather
 
     rows = None
+    interleave = None
     if args.rows is not None:
         if world != 1:
             raise SystemExit("--rows applies to one GPU only")
         rows = tuple(int(v) for v in args.rows.split(":"))
         if not (0 <= rows[0] < rows[1] <= H):
             raise SystemExit("--rows Y0:Y1 must lie inside the frame")
+    ilv_rows = args.interleave if args.interleave is not None else (8 if (world > 1 and args.kernel == "restart") else 0)
+    if args.as_rank is not None:
+        if world != 1:
+            raise SystemExit("--as-rank applies to one GPU only")
+        pr, pn = (int(v) for v in args.as_rank.split("/"))
+        if ilv_rows:
+            interleave = (pn, pr, ilv_rows)
+        else:
+            rows = P.row_bands(H, pn)[pr]
+    elif world > 1 and ilv_rows:
+        interleave = (world, rank, ilv_rows)
     wl = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, n_slots, args.share, not args.sequential,
-                  local_rank, world, rank, gather, rows)
+                  local_rank, world, rank, gather, rows, interleave)
+    proxy = rows is not None or (interleave is not None and world == 1)
     dt, step_ms = wl.run(args.steps, args.warmup)
     frames_per_launch = wl.frames_per_launch
     launches_per_step = spp // frames_per_launch
     # one step = launches_per_step megakernel launches (+ the small resolve kernel when batched) back to back on its stream
     kern_ms = step_ms / launches_per_step
-    value = W * (H if rows is None else rows[1] - rows[0]) * spp * args.steps / dt / 1e6
+    value = W * (wl.my_rows if proxy else H) * spp * args.steps / dt / 1e6
     info = wl.info
     stats = wl.trace_stats()
     checksum = wl.checksum()
     y0, y1 = wl.y0, wl.y1
-    samples_per_launch = (y1 - y0) * W * frames_per_launch
-    compulsory_launch = 28 * (y1 - y0) * W * frames_per_launch + hs.scene_bytes()
+    samples_per_launch = wl.my_rows * W * frames_per_launch
+    compulsory_launch = 28 * wl.my_rows * W * frames_per_launch + hs.scene_bytes()
 
     extra = {}
-    is_headline = (W, H, spp, B, args.tessellate, args.aperture, args.atrium, rows) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None, False, None)
-    if world == 1 and not args.no_extra and not force_gather and rows is None:
+    is_headline = (W, H, spp, B, args.tessellate, args.aperture, args.atrium, proxy) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None, False, False)
+    if world == 1 and not args.no_extra and not force_gather and not proxy:
         k2 = max(4, args.steps // 2)
         # (a) the same batched launch, one at a time: a frame's latency and the unpipelined rate
         if n_slots > 1:
@@ -449,10 +477,12 @@ def main():
             "config": {"workload": f"{os.path.basename(args.scene)}" + (f" x{args.tessellate}^2 tessellation" if args.tessellate > 1 else "")
                                    + (" (generated, 264 832 triangles)" if args.atrium else "")
                                    + f" {W}x{H} {spp} spp {B} bounces" + cfg_tag
-                                   + (f", rows [{rows[0]},{rows[1]}) only" if rows is not None else ""),
+                                   + (f", rows [{rows[0]},{rows[1]}) only" if rows is not None else "")
+                                   + (f", interleaved {interleave[2]}-row bands of rank {interleave[1]}/{interleave[0]} only" if (proxy and interleave) else ""),
                        "kernel": args.kernel, "launches_per_frame": launches_per_step, "frames_per_launch": frames_per_launch,
                        "faces": info["n_faces"], "bvh_nodes": info["n_nodes"], "frames_in_flight": n_slots,
-                       "parallelism": f"rows/{world}" + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
+                       "parallelism": (f"rows/{world}" if interleave is None or world == 1 else f"interleaved {interleave[2]}-row bands over {world} ranks")
+                                      + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
             "roofline": roof,
             "rgba_checksum_rank0_band": checksum,
         }
@@ -464,8 +494,17 @@ def main():
     if bg is not None and rank == 0:
         # the gathered frame must equal rank 0's own band in its rows (cheap self-check of the collective)
         frame = bg.assemble()
-        g0 = 0 if rows is not None else y0      # a --rows band is gathered as a frame of its own
-        assert torch.equal(frame[g0:g0 + (y1 - y0)], wl.slots[0][0].surface), "gathered frame does not contain rank 0's band"
+        mine = wl.slots[0][0].surface
+        if world == 1:                             # (a proxy band is gathered as a frame of its own)
+            ok = torch.equal(frame[:wl.my_rows], mine)
+        elif interleave is not None:
+            ok, local = True, 0
+            for b, e in P.interleaved_bands(H, world, rank, interleave[2]):
+                ok = ok and torch.equal(frame[b:e], mine[local:local + (e - b)])
+                local += e - b
+        else:
+            ok = torch.equal(frame[y0:y1], mine)
+        assert ok, "gathered frame does not contain rank 0's rows"
     if world > 1 or force_gather:
         dist.barrier()
         dist.destroy_process_group()

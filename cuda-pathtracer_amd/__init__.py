@@ -10,9 +10,9 @@ from .native import (KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, KERNEL_BVH_PER
                      PtamdError)
 from .scene import (HostScene, cubemap_for_scene, cubemap_from_color, cubemap_from_cross,
                     FACE_DTYPE, MATERIAL_DTYPE, LIGHT_DTYPE, TEXTURE_DTYPE, CAMERA_DTYPE)
-from .render import (Context, FrameRenderer, host_bvh_trace, host_bvh4_trace, wang_hash, REFERENCE_BOUNCES,
+from .render import (Context, FrameRenderer, host_bvh_trace, host_bvh4_trace, interleaved_rows, wang_hash, REFERENCE_BOUNCES,
                      POST_NONE, POST_GRAYSCALE, POST_SEPIA, POST_INVERT)
-from .tiles import row_bands, band_of_rank, BandGather
+from .tiles import row_bands, band_of_rank, BandGather, interleaved_bands
 from .synthetic import tessellate
 from .image import save_ppm, load_ppm, save_png
 from .images import pil_image_loader, ldr_to_float, load_image, load_image8, native_image_loader, resize_float

@@ -245,6 +245,9 @@ struct KParams {
   const float4* nodes4;
   uint32_t n_nodes4;
   uint32_t stack_lds_entries, stack_spill_entries;
+  // interleaved bands of a multi-GPU split (restart kernel, band-local buffers): 0/1 = off
+  uint32_t ilv_ranks, ilv_rank, ilv_rows;
+  uint32_t y_limit;   // restart kernel: frame rows >= this are outside the launch (row_end; the frame height for interleaved bands)
   uint32_t treelet_nodes;   // the first nodes of nodes4 (top of the tree) are staged in LDS in front of the stacks
   uint2* stack_spill;
   uint32_t walk_min4;

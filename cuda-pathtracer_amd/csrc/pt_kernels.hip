@@ -1215,6 +1215,7 @@ __global__ void __launch_bounds__(PT_RS_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_
   float r1 = 0.f;
   // wave-uniform: the pool holds the paths of ONE tile, entries [pool_rd, 64) not yet handed out
   uint32_t pool_rd = 64u, tile_x0 = 0, tile_y0 = 0, tile_k = 0;
+  uint32_t tile_row_delta = 0;   // (frame row) - (row of the launch's buffers + row_begin): non-zero for interleaved bands
   uint32_t tile = 0, tile_end = 0;
   uint32_t ticket = blockIdx.x * (PT_RS_THREADS / 64u) + (threadIdx.x >> 6);
   uint32_t head = blockIdx.x & 7u, dry = 0;
@@ -1249,11 +1250,22 @@ __global__ void __launch_bounds__(PT_RS_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_
         tile_k = tile / p.n_tiles;
         const uint32_t tl = tile - tile_k * p.n_tiles;
         tile_x0 = (tl % p.tiles_x) * PT_TILE_W;
-        tile_y0 = p.row_begin + (tl / p.tiles_x) * PT_TILE_H;
+        {
+          const uint32_t local_y0 = (tl / p.tiles_x) * PT_TILE_H;   // row inside this launch's share of the frame
+          if (p.ilv_ranks > 1u) {
+            // interleaved bands: band j of ilv_rows rows belongs to rank j % ilv_ranks; this launch renders
+            // the bands of rank ilv_rank and stores them one after the other
+            const uint32_t b = local_y0 / p.ilv_rows, within = local_y0 - b * p.ilv_rows;
+            tile_y0 = (b * p.ilv_ranks + p.ilv_rank) * p.ilv_rows + within;
+          } else {
+            tile_y0 = p.row_begin + local_y0;
+          }
+          tile_row_delta = tile_y0 - (p.row_begin + local_y0);
+        }
         ++tile;
         {
           const uint32_t x = tile_x0 + (lane & (PT_TILE_W - 1u)), y = tile_y0 + (lane >> PT_TILE_W_LOG2);
-          if (x < p.width && y < p.row_end) {
+          if (x < p.width && y < p.y_limit) {
             Path fresh;
             path_begin(p, x, y, fresh, tile_k);
             pool_store(slab, lane, fresh);
@@ -1267,12 +1279,14 @@ __global__ void __launch_bounds__(PT_RS_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_
       if (idle && rank < avail) {
         const uint32_t e = pool_rd + rank;
         const uint32_t x = tile_x0 + (e & (PT_TILE_W - 1u)), y = tile_y0 + (e >> PT_TILE_W_LOG2);
-        if (x < p.width && y < p.row_end) {   // entries of pixels outside the frame were never written: skip them
+        if (x < p.width && y < p.y_limit) {   // entries of pixels outside the frame were never written: skip them
           pool_load(slab, e, st);
           st.throughput = mk3(1.0f);
           st.acc = mk3(0.0f);
           st.specular_col = 0.0f;
-          st.xy = x | (y << 16);
+          // the path is done with its frame coordinates (seed and ray were made in path_begin): from here on `y` is
+          // the row its sample is parked at, row_begin + the row inside the launch's buffers
+          st.xy = x | ((y - tile_row_delta) << 16);
           st.bk = tile_k << 16;
           idle = false;
           walking = false;

@@ -159,6 +159,15 @@ int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
   if (l->frame_count > 1 && l->moved) { set_error("ptamd_raytrace: batched frames must be static (moved = 0)"); return PTAMD_ERR_ARG; }
   if (l->kernel > PTAMD_KERNEL_BVH_RESTART) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
   if (l->machine_share > 64) { set_error("ptamd_raytrace: machine_share out of range (<= 64)"); return PTAMD_ERR_ARG; }
+  if (l->interleave_ranks > 1) {
+    if (l->interleave_rank >= l->interleave_ranks || l->interleave_rows == 0 || l->interleave_rows % 8u != 0 || l->interleave_rows > 4096 ||
+        !l->band_local_buffers || l->row_begin != 0 || l->row_end != l->height || l->moved ||
+        (l->kernel != PTAMD_KERNEL_AUTO && l->kernel != PTAMD_KERNEL_BVH_RESTART)) {
+      set_error("ptamd_raytrace: interleaved bands need rank < ranks, rows a multiple of 8, band-local buffers, the whole frame as row range, "
+                "a static frame and the default kernel");
+      return PTAMD_ERR_ARG;
+    }
+  }
   return PTAMD_OK;
 }
 
@@ -261,7 +270,18 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     const bool restart = which == PTAMD_KERNEL_BVH_RESTART;
     const uint32_t count = l->frame_count > 1 ? l->frame_count : 1u;
 
-    const uint32_t rows = l->row_end - l->row_begin;
+    uint32_t rows = l->row_end - l->row_begin;
+    if (l->interleave_ranks > 1u) {
+      if (!restart) { set_error("ptamd_raytrace: interleaved bands need the restart kernel behind PTAMD_KERNEL_AUTO"); return PTAMD_ERR_ARG; }
+      rows = ptamd_interleaved_rows(l->height, l->interleave_ranks, l->interleave_rank, l->interleave_rows);
+      p.ilv_ranks = l->interleave_ranks; p.ilv_rank = l->interleave_rank; p.ilv_rows = l->interleave_rows;
+      // the launch's buffers hold `rows` rows: parked samples and the resolve pass address them as the band [0, rows)
+      // with band-local buffers; only the restart kernel's tile -> frame-row map knows about the interleaving
+      p.row_begin = 0; p.row_end = rows;
+      p.tfb_row0 = l->height - rows;
+      p.surf_row0 = 0;
+    }
+    p.y_limit = l->row_end;
     p.tiles_x = (l->width + PT_TILE_W - 1u) / PT_TILE_W;
     p.n_tiles = p.tiles_x * ((rows + PT_TILE_H - 1u) / PT_TILE_H);
     if (p.n_tiles == 0) return PTAMD_OK;
@@ -380,6 +400,15 @@ extern "C" {
 
 const char* ptamd_get_last_error(void) { return g_last_error.c_str(); }
 const char* ptamd_version(void) { return "ptamd 0.1 (gfx950)"; }
+
+uint32_t ptamd_interleaved_rows(uint32_t height, uint32_t ranks, uint32_t rank, uint32_t band_rows)
+{
+  if (ranks == 0 || rank >= ranks || band_rows == 0) return 0;
+  uint32_t rows = 0;
+  for (uint64_t y0 = (uint64_t)rank * band_rows; y0 < height; y0 += (uint64_t)ranks * band_rows)
+    rows += (uint32_t)(y0 + band_rows <= height ? band_rows : height - y0);
+  return rows;
+}
 
 uint32_t ptamd_wang_hash(uint32_t a)
 {

@@ -70,7 +70,8 @@ class Launch(C.Structure):
                 ("width", C.c_uint32), ("height", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
                 ("frame_nb", C.c_uint32), ("bounces", C.c_uint32), ("moved", C.c_int32), ("post_id", C.c_uint32),
                 ("kernel", C.c_uint32), ("band_local_buffers", C.c_uint32), ("frame_count", C.c_uint32),
-                ("machine_share", C.c_uint32)]
+                ("machine_share", C.c_uint32),
+                ("interleave_ranks", C.c_uint32), ("interleave_rank", C.c_uint32), ("interleave_rows", C.c_uint32)]
 
 
 class TraceStats(C.Structure):
@@ -128,6 +129,7 @@ SIGNATURES = {
     "ptamd_raytrace_ex": (C.c_int, [C.c_void_p, C.POINTER(Launch)]),
     "ptamd_reset_frame_counter": (C.c_int, [C.c_void_p]),
     "ptamd_wang_hash": (C.c_uint32, [C.c_uint32]),
+    "ptamd_interleaved_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "ptamd_raytrace_stats": (C.c_int, [C.c_void_p, C.POINTER(Launch), C.POINTER(TraceStats)]),
     "ptamd_scene_info_get": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(SceneInfo)]),
     "ptamd_device_error_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

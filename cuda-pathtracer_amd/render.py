@@ -116,7 +116,9 @@ class Context:
                     width: int, height: int, frame_nb: int, bounces: int = REFERENCE_BOUNCES,
                     moved: bool = False, post_id: int = POST_NONE, stream=None,
                     rows: Optional[tuple] = None, kernel: int = N.KERNEL_AUTO,
-                    band_local_buffers: bool = False, frame_count: int = 1, machine_share: int = 0) -> N.Launch:
+                    band_local_buffers: bool = False, frame_count: int = 1, machine_share: int = 0,
+                    interleave: Optional[tuple] = None) -> N.Launch:
+        """interleave = (ranks, rank, band_rows): render the interleaved bands of `rank` (ptamd_launch.interleave_*)."""
         l = N.Launch()
         l.surface_rgba8 = _ptr(array)
         l.temporal_framebuffer = _ptr(temporal_framebuffer)
@@ -130,6 +132,8 @@ class Context:
         l.band_local_buffers = 1 if band_local_buffers else 0
         l.frame_count = frame_count
         l.machine_share = machine_share
+        if interleave is not None:
+            l.interleave_ranks, l.interleave_rank, l.interleave_rows = interleave
         return l
 
     def raytrace_ex(self, launch: N.Launch) -> None:
@@ -182,6 +186,11 @@ def host_bvh4_trace(scene: HostScene, rays: np.ndarray):
     return out, counters[0], counters[1], counters[2]
 
 
+def interleaved_rows(height: int, ranks: int, rank: int, band_rows: int) -> int:
+    """Rows the interleaved bands of `rank` hold (ptamd_interleaved_rows)."""
+    return N.load().ptamd_interleaved_rows(height, ranks, rank, band_rows)
+
+
 def wang_hash(a: int) -> int:
     return N.load().ptamd_wang_hash(a & 0xFFFFFFFF)
 
@@ -192,14 +201,23 @@ class FrameRenderer:
     296-300).  Buffers are torch tensors on the context's device."""
 
     def __init__(self, ctx: Context, scene_id: int, cubemap_id: int, cam: N.Camera, width: int, height: int,
-                 rows: Optional[tuple] = None, band_local: bool = False, machine_share: int = 0):
+                 rows: Optional[tuple] = None, band_local: bool = False, machine_share: int = 0,
+                 interleave: Optional[tuple] = None):
+        """interleave = (ranks, rank, band_rows): this renderer owns the interleaved bands of `rank` (band j of the frame
+        belongs to rank j % ranks); its buffers hold those bands one after the other."""
         import torch
         self.ctx, self.scene_id, self.cubemap_id, self.cam = ctx, scene_id, cubemap_id, cam
         self.width, self.height = width, height
         self.rows = rows if rows is not None else (0, height)
         self.band_local = band_local
         self.machine_share = machine_share   # > 1: this renderer shares the GPU with that many launches in flight
+        self.interleave = interleave
+        if interleave is not None:
+            self.band_local = band_local = True
+            self.rows = (0, height)
         n_rows = (self.rows[1] - self.rows[0]) if band_local else height
+        if interleave is not None:
+            n_rows = interleaved_rows(height, *interleave)
         dev = torch.device("cuda", ctx.device)
         self.surface = torch.zeros((n_rows, width, 4), dtype=torch.uint8, device=dev)
         self.accum = torch.zeros((n_rows, width, 3), dtype=torch.float32, device=dev)
@@ -216,12 +234,14 @@ class FrameRenderer:
             l = self.ctx.make_launch(self.surface, self.accum, self.scene_id, self.cubemap_id, self.cam,
                                      self.width, self.height, frame_nb=first_frame, bounces=bounces, post_id=post_id,
                                      stream=stream, rows=self.rows, kernel=kernel,
-                                     band_local_buffers=self.band_local, frame_count=spp, machine_share=self.machine_share)
+                                     band_local_buffers=self.band_local, frame_count=spp, machine_share=self.machine_share,
+                                     interleave=self.interleave)
             self.ctx.raytrace_ex(l)
             return
         for k in range(first_frame, first_frame + spp):
             l = self.ctx.make_launch(self.surface, self.accum, self.scene_id, self.cubemap_id, self.cam,
                                      self.width, self.height, frame_nb=k, bounces=bounces, post_id=post_id,
                                      stream=stream, rows=self.rows, kernel=kernel,
-                                     band_local_buffers=self.band_local, machine_share=self.machine_share)
+                                     band_local_buffers=self.band_local, machine_share=self.machine_share,
+                                     interleave=self.interleave)
             self.ctx.raytrace_ex(l)

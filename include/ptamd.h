@@ -239,9 +239,18 @@ typedef struct {
                                   Launches in flight on different streams may share one context: batched launches park
                                   their samples in a per-stream scratch owned by the context.  Calls on one context must
                                   still come from one host thread at a time (as for the reference's raytrace()) */
+  /* Interleaved bands of a multi-GPU split (0 or 1 rank: off).  The frame is cut into bands of interleave_rows rows (a
+   * multiple of 8); band j belongs to rank j % interleave_ranks; this launch renders the bands of interleave_rank and
+   * stores them one after the other in band-local buffers (band_local_buffers must be 1, row_begin 0, row_end height,
+   * kernel PTAMD_KERNEL_AUTO / _BVH_RESTART).  Expensive and cheap parts of the picture are thereby spread over all
+   * ranks; pixels are the same as in any other split (seeds come from frame coordinates). */
+  uint32_t interleave_ranks, interleave_rank, interleave_rows;
 } ptamd_launch;
 
 int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch);
+/* Rows an interleaved launch renders (= rows its band-local buffers must hold): the bands j = rank, rank + ranks, ... of
+ * band_rows rows each, the last band of the frame possibly shorter. */
+uint32_t ptamd_interleaved_rows(uint32_t height, uint32_t ranks, uint32_t rank, uint32_t band_rows);
 int ptamd_reset_frame_counter(ptamd_context* ctx);
 uint32_t ptamd_wang_hash(uint32_t a); /* raytrace.cu:275-285 */
 

@@ -14,27 +14,30 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--ranks", type=int, nargs="+", default=[8, 4, 2])
 ap.add_argument("--in-flight", type=int, nargs="+", default=[1, 2, 3])
 ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--interleave", type=int, default=0, help="interleaved bands of this many rows instead of contiguous bands")
 ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_band_proxy.json"))
 args = ap.parse_args()
 sys.path.insert(0, ROOT)
 import cuda_pathtracer_amd as P  # noqa: E402  (row_bands only; no GPU use in this process)
 
 H = 1080
-res = {"frame": "indoor.scene 1920x1080 4 spp 4 bounces", "kernel": "restart (default)", "gather": "RCCL all-gather forced (1-rank communicator)",
+res = {"frame": "indoor.scene 1920x1080 4 spp 4 bounces", "kernel": "restart (default)",
+       "assignment": f"interleaved {args.interleave}-row bands (band j -> rank j % N)" if args.interleave else "contiguous bands", "gather": "RCCL all-gather forced (1-rank communicator)",
        "steps": args.steps, "splits": []}
 for n in args.ranks:
     for fif in args.in_flight:
         bands = []
-        for (y0, y1) in P.row_bands(H, n):
+        for r, (y0, y1) in enumerate(P.row_bands(H, n)):
             env = dict(os.environ, PTAMD_BENCH_FORCE_GATHER="1")
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", f"{y0}:{y1}", "--steps", str(args.steps),
-                                  "--warmup", "5", "--no-cpu-baseline", "--no-extra", "--frames-in-flight", str(fif)],
-                                 env=env, capture_output=True, text=True, timeout=300)
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--as-rank", f"{r}/{n}", "--interleave", str(args.interleave),
+                                  "--steps", str(args.steps), "--warmup", "5", "--no-cpu-baseline", "--no-extra",
+                                  "--frames-in-flight", str(fif)], env=env, capture_output=True, text=True, timeout=300)
             if out.returncode != 0:
                 print(out.stderr[-2000:], file=sys.stderr)
-                raise SystemExit(f"bench failed for band {y0}:{y1}")
+                raise SystemExit(f"bench failed for rank {r}/{n}")
             d = json.loads(out.stdout.strip().splitlines()[-1])
-            bands.append({"rows": [y0, y1], "ms_per_frame": d["ms_per_step"], "kernel_ms_per_launch": d["roofline"]["kernel_ms_per_launch"]})
+            bands.append({"rank": r, "rows": [y0, y1] if not args.interleave else f"bands {r}, {r + n}, ... of {args.interleave} rows",
+                          "ms_per_frame": d["ms_per_step"], "kernel_ms_per_launch": d["roofline"]["kernel_ms_per_launch"]})
         ms = [b["ms_per_frame"] for b in bands]
         mean = sum(ms) / len(ms)
         entry = {"ranks": n, "frames_in_flight": fif, "bands": bands, "max_ms": max(ms), "mean_ms": round(mean, 4),

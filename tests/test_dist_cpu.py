@@ -30,6 +30,31 @@ def test_row_bands_partition(P):
         P.row_bands(10, 0)
 
 
+def test_interleaved_bands_partition(P):
+    import torch
+    for h in (1, 7, 16, 135, 1080, 2160, 1081):
+        for w in (1, 2, 3, 8):
+            for br in (8, 16, 24):
+                seen = np.zeros(h, dtype=np.int32)
+                for r in range(w):
+                    bands = P.interleaved_bands(h, w, r, br)
+                    assert sum(e - b for b, e in bands) == P.interleaved_rows(h, w, r, br)      # == the C-ABI's count
+                    for b, e in bands:
+                        assert b % br == 0 and (b // br) % w == r and 0 < e - b <= br
+                        seen[b:e] += 1
+                assert (seen == 1).all()
+    # assemble(): every frame row comes from the right rank's local row (checked without a collective)
+    h, w, br = 53, 3, 8
+    bgs = [P.BandGather(h, 5, w, r, torch.device("cpu"), interleave=br) for r in range(w)]
+    frame = torch.arange(h * 5 * 4, dtype=torch.int64).reshape(h, 5, 4).to(torch.uint8)
+    recv = torch.zeros_like(bgs[0].recv)
+    for r in range(w):
+        local = torch.cat([frame[b:e] for b, e in P.interleaved_bands(h, w, r, br)], dim=0)
+        recv[r * bgs[0].max_rows: r * bgs[0].max_rows + len(local)] = local
+    bgs[0].recv.copy_(recv)
+    assert torch.equal(bgs[0].assemble(), frame)
+
+
 WORKER = textwrap.dedent("""
     import os, sys
     sys.path[:0] = [{root!r}, os.path.join({root!r}, "oracle")]
@@ -92,19 +117,23 @@ GPU_WORKER = textwrap.dedent("""
     hs = P.HostScene.load(os.path.join({root!r}, "assets", "indoor.scene"))
     cube = P.cubemap_for_scene(hs)
     bg = P.BandGather(H, W, world, rank, torch.device("cpu"))
+    bgi = P.BandGather(H, W, world, rank, torch.device("cpu"), interleave=16)
     y0, y1 = bg.bands[rank]
     with P.Context(0) as ctx:                                  # both ranks share the box's one GPU
         ctx.setup_function_tables()
         sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(cube)
         fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True, machine_share=3)
         fr.render(spp=spp, bounces=B, batched=True)
+        fri = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, machine_share=3, interleave=(world, rank, 16))
+        fri.render(spp=spp, bounces=B, batched=True)
         torch.cuda.synchronize()
         bg.gather(fr.surface.cpu())
+        bgi.gather(fri.surface.cpu())
         if rank == 0:
             full = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H)
             full.render(spp=spp, bounces=B)
             torch.cuda.synchronize()
-            np.save({out!r}, np.stack([bg.assemble().numpy(), full.surface.cpu().numpy()]))
+            np.save({out!r}, np.stack([bg.assemble().numpy(), full.surface.cpu().numpy(), bgi.assemble().numpy()]))
     dist.barrier()
     dist.destroy_process_group()
 """)
@@ -124,5 +153,6 @@ def test_two_rank_device_render_and_gather_equals_one_gpu_frame(tmp_path):
                            "--master-addr", "127.0.0.1", "--master-port", "29519", str(script)], env=env, cwd=ROOT,
                           timeout=900)
     both = np.load(out)
-    np.testing.assert_array_equal(both[0], both[1])
+    np.testing.assert_array_equal(both[0], both[1])            # contiguous bands
+    np.testing.assert_array_equal(both[2], both[1])            # interleaved 16-row bands
     assert both[0][..., :3].any()

@@ -191,6 +191,42 @@ def test_row_band_split_is_bit_identical(P, gpu_ctx, indoor):
     assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), full_acc, full_rgba, "band launches into full buffers")
 
 
+def test_interleaved_band_split_is_bit_identical(P, gpu_ctx, indoor):
+    """SURVEY §8-e's interleaved assignment (band j of 8/16/24 rows -> rank j % R): every rank's launch renders its bands
+    into band-local buffers; put back in frame order, surfaces AND accumulators equal the single-launch frame, for
+    sequential and batched launches, ragged frame heights included."""
+    import torch
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    for (W, H, spp, B) in ((200, 121, 2, 4), (1920, 1080, 4, 4)):
+        full_acc, full_rgba = gpu_render(P, gpu_ctx, indoor, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
+        for world, br in ((2, 16), (3, 8), (8, 16), (5, 24)):
+            rgba = np.zeros_like(full_rgba)
+            acc = np.zeros_like(full_acc)
+            for rank in range(world):
+                fr = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H, interleave=(world, rank, br))
+                fr.render(spp=spp, bounces=B, batched=batched_ok() and rank % 2 == 0)
+                torch.cuda.synchronize()
+                s, a = fr.surface.cpu().numpy(), fr.accum.cpu().numpy()
+                bands = P.interleaved_bands(H, world, rank, br)
+                assert s.shape[0] == sum(e - b for b, e in bands)
+                local = 0
+                for b, e in bands:
+                    rgba[b:e] = s[local:local + (e - b)]
+                    # the accumulator is stored row-flipped (raytrace.cu:252): local row i lives at rows - 1 - i
+                    acc[H - e:H - b] = a[s.shape[0] - (local + (e - b)):s.shape[0] - local]
+                    local += e - b
+            assert_same(acc, rgba, full_acc, full_rgba, f"interleaved {world} ranks x {br} rows, {W}x{H}")
+    l = gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), W, H, frame_nb=1, band_local_buffers=True,
+                            interleave=(4, 4, 16))
+    with pytest.raises(P.PtamdError):
+        gpu_ctx.raytrace_ex(l)                                   # rank out of range
+    l = gpu_ctx.make_launch(fr.surface, fr.accum, *ids, indoor.camera_struct(), W, H, frame_nb=1, band_local_buffers=True,
+                            interleave=(4, 1, 12))
+    with pytest.raises(P.PtamdError):
+        gpu_ctx.raytrace_ex(l)                                   # band rows not a multiple of 8
+
+
 def test_batched_frames_equal_consecutive_launches(P, O, gpu_ctx, indoor):
     """ptamd_launch.frame_count = N: one launch + resolve == N consecutive raytrace() calls, bit for bit
     (accumulator and final surface), also on top of a non-zero accumulator and for row bands."""
