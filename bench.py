@@ -189,9 +189,9 @@ class Workload:
         self.P, self.torch, self.dist = P, torch, dist
         self.W, self.H, self.spp, self.B = W, H, spp, B
         self.world, self.rank = world, rank
-        self.kernel = {"bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
+        self.kernel = {"auto": P.KERNEL_AUTO, "bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
                        "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT, "restart": P.KERNEL_BVH_RESTART}[kernel_name]
-        self.batched = batched and kernel_name in ("persistent", "split", "restart") and spp > 1
+        self.batched = batched and kernel_name in ("auto", "persistent", "split", "restart") and spp > 1
         self.n_slots = n_slots
         self.hs = hs
         self.dev = torch.device("cuda", local_rank)
@@ -395,7 +395,8 @@ def main():
             extra["ms_per_frame"] = round(step_ms, 4)
         # (b) SURVEY §8-d's literal metric: spp launches per frame, one frame at a time
         if not args.sequential:
-            seq = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, 1, False, False, local_rank)
+            # (PTAMD_KERNEL_AUTO: what a host that calls raytrace() once per spp gets — the persistent kernel on this scene)
+            seq = Workload(P, torch, dist, hs, cube, W, H, spp, B, "auto" if args.kernel == "restart" else args.kernel, 1, False, False, local_rank)
             qdt, q_ms = seq.run(k2, 2)
             seq.close()
             extra["value_sequential"] = round(W * H * spp * k2 / qdt / 1e6, 3)

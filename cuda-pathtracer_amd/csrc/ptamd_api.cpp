@@ -71,6 +71,7 @@ struct ptamd_context {
   struct SampleScratch { void* stream = nullptr; float* buf = nullptr; size_t bytes = 0; };
   std::vector<SampleScratch> sample_scratch;
   uint32_t default_kernel = PTAMD_KERNEL_BVH_RESTART; // what PTAMD_KERNEL_AUTO means
+  bool default_kernel_is_builtin = true;              // false once PTAMD_DEFAULT_KERNEL pinned it
   uint32_t refill_min = 0; // 0 = choose per launch (see do_launch); PTAMD_REFILL_MIN pins it
   // restart kernel: a round of walks ends once fewer than min(round_min, entering lanes / round_div) lanes are unfinished
   // measured (scripts/gpu_r2_sweep.sh, 1080p x 4 spp x 4 bounces): round_min 16-32 and walk_min 4-6 are a flat optimum
@@ -228,6 +229,12 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   const size_t lds = kind == 1 ? s.info.lds_bytes_brute : s.info.lds_bytes_bvh;
   // the LDS copy of a BVH addresses its boxes with 15 bits (pt_kernels.hip: stage_scene): 32 bytes per node, nodes first
   const bool resident = lds <= kLdsBudget && (kind == 1 || s.n_nodes <= kCompactMaxNodes);
+  // PTAMD_KERNEL_AUTO, one frame per launch (the reference's interactive loop, ptamd_raytrace) on an LDS-resident scene:
+  // the persistent kernel writes the surface itself, the restart kernel would add its resolve pass to every launch
+  // (1080p, one launch per spp: 5.79 vs 5.27 Gsamples/s).  Batched frames, big scenes and interleaved bands: restart.
+  if (l->kernel == PTAMD_KERNEL_AUTO && which == PTAMD_KERNEL_BVH_RESTART && ctx->default_kernel_is_builtin && l->frame_count <= 1 &&
+      resident && l->interleave_ranks <= 1)
+    which = PTAMD_KERNEL_BVH_PERSISTENT;
   hipStream_t stream = static_cast<hipStream_t>(l->stream);
   hipError_t e;
   if (far_origin && s.n_faces != 0 && l->frame_count > 1) {
@@ -449,7 +456,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   }
   if (const char* e = std::getenv("PTAMD_DEFAULT_KERNEL")) { // tuning knob: 1..6
     int v = std::atoi(e);
-    if (v >= 1 && v <= 6) ctx->default_kernel = (uint32_t)v;
+    if (v >= 1 && v <= 6) { ctx->default_kernel = (uint32_t)v; ctx->default_kernel_is_builtin = false; }
   }
   if (const char* e = std::getenv("PTAMD_ROUND_MIN")) { // tuning knob
     int v = std::atoi(e);

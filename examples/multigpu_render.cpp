@@ -11,9 +11,11 @@
 //
 //   hipcc -std=c++17 -O2 -Iinclude examples/multigpu_render.cpp -Lcuda-pathtracer_amd -lptamd -lrccl \
 //         -Wl,-rpath,$PWD/cuda-pathtracer_amd -o multigpu_render
-//   ./multigpu_render assets/indoor.scene 1920 1080 4 4 out.png [--ranks N] [--frames F] [--check]
+//   ./multigpu_render assets/indoor.scene 1920 1080 4 4 out.png [--ranks N] [--frames F] [--interleave ROWS] [--check]
 //        SCENE WIDTH HEIGHT SPP BOUNCES OUT   --ranks: GPUs to use (default: all)   --frames: timed frames (default 20)
-//        --check: rank 0 also renders the whole frame alone and compares (exit code 3 on any difference)
+//        --interleave: ranks own interleaved bands of ROWS rows (band j -> rank j % N; default 8, 0 = one contiguous band
+//        each): the parts of a picture differ in cost, interleaving spreads them   --check: rank 0 also renders the whole
+//        frame alone and compares (exit code 3 on any difference)
 #include "ptamd.h"
 
 #include <hip/hip_runtime.h>
@@ -34,6 +36,7 @@ struct Options {
   std::string scene, out;
   unsigned width = 1920, height = 1080, spp = 4, bounces = 4;
   int ranks = 0, frames = 20;
+  unsigned interleave = 8;
   bool check = false;
 };
 
@@ -93,12 +96,20 @@ void rank_main(int rank, int world, Shared* sh)
   PT_OK(ptamd_upload_scene(ctx, sh->desc, &scene_id));
   PT_OK(ptamd_upload_cubemap(ctx, sh->cube->data(), sh->cube_size, &cubemap_id));
 
+  const bool ilv = o.interleave != 0 && world > 1;
   unsigned y0 = 0, y1 = 0;
   band_of(o.height, world, rank, &y0, &y1);
+  if (ilv) { y0 = 0; y1 = ptamd_interleaved_rows(o.height, (uint32_t)world, (uint32_t)rank, o.interleave); }   // rows of this rank's buffers
   unsigned max_rows = 0;
-  for (int r = 0; r < world; ++r) { unsigned a, b; band_of(o.height, world, r, &a, &b); if (b - a > max_rows) max_rows = b - a; }
+  for (int r = 0; r < world; ++r) {
+    unsigned a, b;
+    band_of(o.height, world, r, &a, &b);
+    const unsigned n = ilv ? ptamd_interleaved_rows(o.height, (uint32_t)world, (uint32_t)r, o.interleave) : b - a;
+    if (n > max_rows) max_rows = n;
+  }
   const size_t band_bytes = (size_t)max_rows * o.width * 4;   // bands are padded to the tallest one: one fixed-size collective
   void *surface = nullptr, *tfb = nullptr, *gathered = nullptr;
+  // (from here on y1 - y0 = the rows this rank's buffers hold)
   PT_OK(ptamd_device_alloc(ctx, band_bytes, &surface));
   PT_OK(ptamd_device_alloc(ctx, (size_t)(y1 - y0) * o.width * 12, &tfb));
   PT_OK(ptamd_device_alloc(ctx, band_bytes * (size_t)world, &gathered));
@@ -111,6 +122,7 @@ void rank_main(int rank, int world, Shared* sh)
   l.width = o.width; l.height = o.height; l.row_begin = y0; l.row_end = y1;
   l.frame_nb = 1; l.bounces = o.bounces; l.moved = 0; l.post_id = 0; l.kernel = PTAMD_KERNEL_AUTO;
   l.band_local_buffers = 1;
+  if (ilv) { l.row_begin = 0; l.row_end = o.height; l.interleave_ranks = (uint32_t)world; l.interleave_rank = (uint32_t)rank; l.interleave_rows = o.interleave; }
   l.frame_count = o.spp;          // the spp static frames of one picture as ONE launch (== spp consecutive raytrace() calls)
 
   auto frame = [&]() -> bool {
@@ -132,10 +144,22 @@ void rank_main(int rank, int world, Shared* sh)
     // drop the padding rows while copying the gathered bands to the host
     sh->frame.assign((size_t)o.width * o.height * 4, 0);
     for (int r = 0; r < world; ++r) {
-      unsigned a, b;
-      band_of(o.height, world, r, &a, &b);
-      PT_OK(ptamd_device_to_host(ctx, sh->frame.data() + (size_t)a * o.width * 4,
-                                 static_cast<char*>(gathered) + (size_t)r * band_bytes, (size_t)(b - a) * o.width * 4, stream));
+      if (!ilv) {
+        unsigned a, b;
+        band_of(o.height, world, r, &a, &b);
+        PT_OK(ptamd_device_to_host(ctx, sh->frame.data() + (size_t)a * o.width * 4,
+                                   static_cast<char*>(gathered) + (size_t)r * band_bytes, (size_t)(b - a) * o.width * 4, stream));
+        continue;
+      }
+      // rank r's buffer holds its bands r, r + world, ... one after the other
+      size_t local = 0;
+      for (unsigned a = (unsigned)r * o.interleave; a < o.height; a += (unsigned)world * o.interleave) {
+        const unsigned b = a + o.interleave < o.height ? a + o.interleave : o.height;
+        PT_OK(ptamd_device_to_host(ctx, sh->frame.data() + (size_t)a * o.width * 4,
+                                   static_cast<char*>(gathered) + (size_t)r * band_bytes + local * o.width * 4,
+                                   (size_t)(b - a) * o.width * 4, stream));
+        local += b - a;
+      }
     }
     if (o.check) {
       void *full_surface = nullptr, *full_tfb = nullptr;
@@ -145,6 +169,7 @@ void rank_main(int rank, int world, Shared* sh)
       ptamd_launch f = l;
       f.surface_rgba8 = full_surface; f.temporal_framebuffer = static_cast<float*>(full_tfb);
       f.row_begin = 0; f.row_end = o.height; f.band_local_buffers = 0;
+      f.interleave_ranks = f.interleave_rank = f.interleave_rows = 0;
       PT_OK(ptamd_raytrace_ex(ctx, &f));
       std::vector<unsigned char> ref((size_t)o.width * o.height * 4);
       PT_OK(ptamd_device_to_host(ctx, ref.data(), full_surface, ref.size(), stream));
@@ -176,10 +201,14 @@ int main(int argc, char** argv)
   for (int i = 7; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--ranks") && i + 1 < argc) o.ranks = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) o.frames = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--interleave") && i + 1 < argc) o.interleave = (unsigned)std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--check")) o.check = true;
     else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
-  if (o.width == 0 || o.height == 0 || o.spp == 0 || o.bounces == 0 || o.frames < 1) { std::fprintf(stderr, "bad frame parameters\n"); return 2; }
+  if (o.width == 0 || o.height == 0 || o.spp == 0 || o.bounces == 0 || o.frames < 1 || o.interleave % 8u != 0) {
+    std::fprintf(stderr, "bad frame parameters (--interleave must be a multiple of 8)\n");
+    return 2;
+  }
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { std::fprintf(stderr, "no HIP device: this host has no CPU fallback\n"); return 1; }
   const int world = o.ranks > 0 ? o.ranks : n_dev;
@@ -235,8 +264,9 @@ int main(int argc, char** argv)
   }
   const double msamples = (double)o.width * o.height * o.spp / (sh.ms_per_frame * 1e-3) / 1e6;
   std::printf("{\"host\": \"c++\", \"n_gpus\": %d, \"frame\": \"%ux%u %u spp %u bounces\", \"ms_per_frame\": %.4f, \"msamples_per_s\": %.1f, "
-              "\"gather\": \"ncclAllGather of RGBA8 row bands\"%s}\n",
+              "\"bands\": \"%s\", \"gather\": \"ncclAllGather of RGBA8 row bands\"%s}\n",
               world, o.width, o.height, o.spp, o.bounces, sh.ms_per_frame, msamples,
+              (o.interleave != 0 && world > 1) ? "interleaved" : "contiguous",
               o.check ? (sh.check_ok ? ", \"check\": \"equals the 1-GPU frame\"" : ", \"check\": \"DIFFERS from the 1-GPU frame\"") : "");
   return o.check && !sh.check_ok ? 3 : 0;
 }

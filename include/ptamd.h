@@ -204,7 +204,8 @@ int ptamd_raytrace(ptamd_context* ctx, void* surface_rgba8, uint32_t scene_id, u
                    float* temporal_framebuffer, int32_t moved, uint32_t post_id);
 
 typedef enum {
-  PTAMD_KERNEL_AUTO = 0,          /* the shipped default: PTAMD_KERNEL_BVH_RESTART */
+  PTAMD_KERNEL_AUTO = 0,          /* the shipped default: PTAMD_KERNEL_BVH_RESTART (PTAMD_KERNEL_BVH_PERSISTENT for single-frame
+                                     launches on scenes that fit in LDS: no resolve pass per launch) */
   PTAMD_KERNEL_BRUTE_FORCE = 1,   /* the reference algorithm: every face, LDS-staged, wave-uniform; 1 thread = 1 pixel */
   PTAMD_KERNEL_BVH = 2,           /* stackless ordered BVH walk, LDS-staged nodes + triangles; 1 thread = 1 pixel */
   PTAMD_KERNEL_BVH_PERSISTENT = 3, /* same walk in persistent waves with mid-path lane refill (ballot + mbcnt) */
