@@ -121,6 +121,8 @@ def test_cpp_multigpu_host_renders_and_gathers(P, tmp_path):
     import subprocess
     import numpy as np
     import torch
+    if os.environ.get("PTAMD_DEFAULT_KERNEL", "6") not in ("3", "5", "6"):
+        pytest.skip("PTAMD_DEFAULT_KERNEL selects a kernel that cannot batch frames")
     exe = _build_multigpu_host(tmp_path)
     out = str(tmp_path / "o.png")
     r = subprocess.run([exe, os.path.join(ROOT, "assets", "indoor.scene"), "320", "180", "4", "4", out, "--ranks", "1",

@@ -124,11 +124,16 @@ GPU_WORKER = textwrap.dedent("""
         sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(cube)
         fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True, machine_share=3)
         fr.render(spp=spp, bounces=B, batched=True)
-        fri = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, machine_share=3, interleave=(world, rank, 16))
+        # interleaved bands are a feature of the default (restart) kernel: under a pinned PTAMD_DEFAULT_KERNEL knob the
+        # second gather repeats the contiguous one
+        ilv_ok = os.environ.get("PTAMD_DEFAULT_KERNEL", "6") == "6"
+        fri = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, machine_share=3, interleave=(world, rank, 16)) if ilv_ok else fr
         fri.render(spp=spp, bounces=B, batched=True)
         torch.cuda.synchronize()
         bg.gather(fr.surface.cpu())
-        bgi.gather(fri.surface.cpu())
+        (bgi if ilv_ok else bg).gather(fri.surface.cpu())
+        if not ilv_ok:
+            bgi = bg
         if rank == 0:
             full = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H)
             full.render(spp=spp, bounces=B)
