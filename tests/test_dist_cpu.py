@@ -102,7 +102,9 @@ def test_bench_gpus_n_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
-    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]      # both ranks got as far as the device check
+    # the ranks got as far as the device check (the launcher may stop the second one as soon as the first has failed)
+    assert r.stderr.count("bench.py needs a GPU") >= 1, r.stderr[-2000:]
+    assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr        # ... under the launcher bench.py started
     assert "must be launched with" not in r.stderr and r.stdout.strip() == ""
 
 
