@@ -40,7 +40,18 @@ oracle-ref:
 	@echo "oracle-ref: $(REF3P_INC) not present, skipped"
 endif
 
-clean:
-	rm -f $(LIB) $(ORACLE) $(REFLIB)
+# optional OpenGL presenter (include/ptamd_gl.h): built only where GL headers and libGL exist; needs a display to RUN
+GLLIB := $(PKG)/libptamd_gl.so
+ifneq ($(wildcard /usr/include/GL/glext.h),)
+gl: $(GLLIB)
+$(GLLIB): $(PKG)/host/gl_presenter.cpp include/ptamd_gl.h include/ptamd.h
+	$(HIPCC) -std=c++17 -O2 -fPIC -shared -Wall -Wextra -Iinclude $< -lGL -o $@
+else
+gl:
+	@echo "gl: no GL headers on this host, skipped"
+endif
 
-.PHONY: all lib oracle oracle-ref clean
+clean:
+	rm -f $(LIB) $(ORACLE) $(REFLIB) $(GLLIB)
+
+.PHONY: all lib oracle oracle-ref gl clean

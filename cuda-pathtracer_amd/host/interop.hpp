@@ -11,13 +11,18 @@
 //     what ptamd_raytrace writes — so the vertical flip of the GL blit is already done and blit() is a straight copy;
 //   * map()/unmap() have nothing to register and return PTAMD_OK (they keep the call sequence of render() intact);
 //   * blit() brings the current buffer to the host (after the stream's pending work) and hands it to the presenter
-//     callback given at construction — a GL application uploads it with glTexSubImage2D / a PBO there, a headless
-//     one writes a file (ptamd_image_save_png) or does nothing;
+//     callback given at construction — a headless host writes a file (ptamd_image_save_png) or does nothing; a host
+//     with a window builds with -DPTAMD_WITH_GL and calls blit(gl_presenter, stream) instead: the optional
+//     libptamd_gl.so (include/ptamd_gl.h) uploads the surface through a HIP-registered pixel buffer and does the
+//     reference's flipped glBlitFramebuffer;
 //   * errors are ptamd_status codes instead of cudaError_t.
 // Header-only; link with -lptamd.
 #pragma once
 
 #include "ptamd.h"
+#ifdef PTAMD_WITH_GL
+#include "ptamd_gl.h"   // optional OpenGL presenter (libptamd_gl.so) for hosts that own a window
+#endif
 
 #include <cstddef>
 #include <cstdint>
@@ -72,6 +77,16 @@ public:
     if (rc == PTAMD_OK && _presenter) _presenter(_host.data(), _width, _height);
     return rc;
   }
+
+#ifdef PTAMD_WITH_GL
+  /// With a window (-DPTAMD_WITH_GL, -lptamd_gl): the reference's blit (interop.cpp:67-72) — the current framebuffer goes
+  /// to the default GL framebuffer through the HIP-GL interop buffer of the presenter, without a host copy.
+  int blit(ptamd_gl_presenter* gl, void* stream = nullptr)
+  {
+    if (!_d_surface[_index] || bytes() == 0) return PTAMD_OK;
+    return ptamd_gl_presenter_present(gl, _d_surface[_index], stream);
+  }
+#endif
 
   int setSize(const unsigned int w, const unsigned int h)
   {

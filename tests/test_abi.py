@@ -138,3 +138,31 @@ def test_cpp_multigpu_host_renders_and_gathers(P, tmp_path):
         torch.cuda.synchronize()
         want = fr.surface.cpu().numpy()[:, :, :3]
     np.testing.assert_array_equal(P.load_image8(out), want)
+
+
+def test_optional_gl_presenter_builds_and_refuses_to_run_without_a_context(P, tmp_path):
+    """include/ptamd_gl.h / libptamd_gl.so — the GL half of driver::Interop (interop.cpp:14-20,36-72,104-116) for hosts
+    that own a window: HIP-GL interop through a registered pixel buffer + the reference's flipped blit.  No display
+    exists on the build box or on an MI355X node, so: it builds and links against libGL and HIP, exports what its header
+    declares, compiles into the C++ Interop mirror, and without a current GL context create() fails with a message."""
+    import subprocess
+    if not os.path.exists("/usr/include/GL/glext.h"):
+        pytest.skip("no GL headers on this host")
+    subprocess.check_call(["make", "-s", "gl"], cwd=ROOT)
+    lib = C.CDLL(os.path.join(ROOT, "cuda-pathtracer_amd", "libptamd_gl.so"))
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ptamd_gl.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(ptamd_gl_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 5
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.ptamd_gl_get_last_error.restype = C.c_char_p
+    h = C.c_void_p()
+    assert lib.ptamd_gl_presenter_create(64, 64, C.byref(h)) == P.native.PTAMD_ERR_ARG and not h.value
+    assert b"no current OpenGL context" in lib.ptamd_gl_get_last_error()
+    assert lib.ptamd_gl_presenter_present(None, None, None) == P.native.PTAMD_ERR_ARG
+    # the C++ mirror of driver::Interop compiles with the GL overload of blit()
+    src = tmp_path / "with_gl.cpp"
+    src.write_text('#define PTAMD_WITH_GL 1\n#include "interop.hpp"\n'
+                   'int f(ptamd_host::Interop& i, ptamd_gl_presenter* g) { return i.blit(g, nullptr); }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-c", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "cuda-pathtracer_amd", "host"), str(src), "-o", str(tmp_path / "with_gl.o")])
