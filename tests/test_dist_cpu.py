@@ -129,8 +129,10 @@ GPU_WORKER = textwrap.dedent("""
         # interleaved bands are a feature of the default (restart) kernel: under a pinned PTAMD_DEFAULT_KERNEL knob the
         # second gather repeats the contiguous one
         ilv_ok = os.environ.get("PTAMD_DEFAULT_KERNEL", "6") == "6"
-        fri = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, machine_share=3, interleave=(world, rank, 16)) if ilv_ok else fr
-        fri.render(spp=spp, bounces=B, batched=True)
+        fri = fr
+        if ilv_ok:
+            fri = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, machine_share=3, interleave=(world, rank, 16))
+            fri.render(spp=spp, bounces=B, batched=True)
         torch.cuda.synchronize()
         bg.gather(fr.surface.cpu())
         (bgi if ilv_ok else bg).gather(fri.surface.cpu())
