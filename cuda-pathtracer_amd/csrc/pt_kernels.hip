@@ -1032,6 +1032,10 @@ struct Stack4 {
   const float4* top;
   uint32_t top_n;
 };
+#ifndef PT_RS4_THREADS
+#define PT_RS4_THREADS 1024     /* workgroup size of the wide-walk instantiation: ONE workgroup per CU, so one copy of the LDS treelet
+                                   (256 / 512 / 1024 threads: atrium 1177 / 1233 / 1278, tessellated indoor 2868 / 2966 / 3081 Msamples/s) */
+#endif
 #ifndef PT_RS4_WAVES_PER_EU
 #define PT_RS4_WAVES_PER_EU 4   /* measured on the atrium (leaf records fetched in one batch): 4 / 5 / 6 waves per SIMD = 1069 / 954 / 798 Msamples/s (5 and 6 spill) */
 #endif
@@ -1177,8 +1181,10 @@ PT_DEV void traverse_round4(const float4* nodes4, const float4* tris, const Stac
 }
 
 template <bool LDS_RESIDENT, bool STATS>
-__global__ void __launch_bounds__(PT_RS_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_EU : PT_RS4_WAVES_PER_EU) pt_megakernel_restart(const KParams p)
+__global__ void __launch_bounds__(LDS_RESIDENT ? PT_RS_THREADS : PT_RS4_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_EU : PT_RS4_WAVES_PER_EU)
+pt_megakernel_restart(const KParams p)
 {
+  constexpr uint32_t THREADS = LDS_RESIDENT ? PT_RS_THREADS : PT_RS4_THREADS;
   extern __shared__ float4 s_mem[];
   const float4* s_nodes;
   const float4* s_tris;
@@ -1187,7 +1193,7 @@ __global__ void __launch_bounds__(PT_RS_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_
   constexpr bool WIDE = !LDS_RESIDENT;
 
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t gwave = blockIdx.x * (PT_RS_THREADS / 64u) + (threadIdx.x >> 6);
+  const uint32_t gwave = blockIdx.x * (THREADS / 64u) + (threadIdx.x >> 6);
   float4* slab = p.pool + (size_t)gwave * 192u;
   Stack4 stk;
   stk.top = s_mem;
@@ -1217,7 +1223,7 @@ __global__ void __launch_bounds__(PT_RS_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_
   uint32_t pool_rd = 64u, tile_x0 = 0, tile_y0 = 0, tile_k = 0;
   uint32_t tile_row_delta = 0;   // (frame row) - (row of the launch's buffers + row_begin): non-zero for interleaved bands
   uint32_t tile = 0, tile_end = 0;
-  uint32_t ticket = blockIdx.x * (PT_RS_THREADS / 64u) + (threadIdx.x >> 6);
+  uint32_t ticket = gwave;
   uint32_t head = blockIdx.x & 7u, dry = 0;
   bool have_ticket = true, exhausted = false;
 
@@ -1858,9 +1864,9 @@ static const void* restart_select(bool lds_resident, bool stats)
                : reinterpret_cast<const void*>(pt_megakernel_restart<false, false>);
 }
 
-uint32_t restart_threads() { return PT_RS_THREADS; }
-// wide walk: resident workgroups per CU the launch bounds aim for (their LDS share holds the waves' stacks)
-uint32_t restart_wide_blocks_per_cu() { return (PT_RS4_WAVES_PER_EU * 256u) / PT_RS_THREADS; }
+uint32_t restart_threads(bool lds_resident) { return lds_resident ? PT_RS_THREADS : PT_RS4_THREADS; }
+// wide walk: resident workgroups per CU the launch bounds aim for (their LDS share holds the treelet and the waves' stacks)
+uint32_t restart_wide_blocks_per_cu() { return (PT_RS4_WAVES_PER_EU * 256u) / PT_RS4_THREADS; }
 
 // lds_bytes: the staged scene when lds_resident, else the stacks of the wide walk
 hipError_t restart_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out)
@@ -1870,7 +1876,7 @@ hipError_t restart_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out)
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, PT_RS_THREADS, lds_bytes);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, (int)restart_threads(lds_resident), lds_bytes);
 }
 
 hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t lds_bytes, bool stats,
@@ -1884,7 +1890,7 @@ hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t
   }
   KParams pc = p;
   void* args[] = { &pc };
-  return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_RS_THREADS), args, lds_bytes, stream);
+  return hipLaunchKernel(fn, dim3(n_blocks), dim3(restart_threads(lds_resident)), args, lds_bytes, stream);
 }
 
 static const void* split_select(bool lds_resident, bool stats)

@@ -21,7 +21,7 @@ uint32_t split_shader_waves();
 hipError_t split_blocks_per_cu(bool lds_resident, size_t scene_lds_bytes, int* out);
 hipError_t launch_megakernel_split(const KParams& p, bool lds_resident, size_t scene_lds_bytes, bool stats,
                                    uint32_t n_blocks, hipStream_t stream);
-uint32_t restart_threads();
+uint32_t restart_threads(bool lds_resident);
 uint32_t restart_wide_blocks_per_cu();
 hipError_t restart_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out);
 hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t lds_bytes, bool stats,

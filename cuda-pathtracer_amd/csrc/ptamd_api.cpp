@@ -77,7 +77,7 @@ struct ptamd_context {
   // measured (scripts/gpu_r2_sweep.sh, 1080p x 4 spp x 4 bounces): round_min 16-32 and walk_min 4-6 are a flat optimum
   uint32_t round_min = 16, round_div = 4; // PTAMD_ROUND_MIN, PTAMD_ROUND_DIV
   uint32_t walk_min = 5;                  // restart kernel: a box phase ends once fewer lanes than this still walk (PTAMD_WALK_MIN)
-  uint32_t treelet_nodes = 341;           // wide walk: nodes of the top of the tree staged in LDS (PTAMD_TREELET)
+  uint32_t treelet_nodes = 640;           // wide walk: nodes of the top of the tree staged in LDS (PTAMD_TREELET; 341 / 700 / 1000: 1268 / 1278 / 1226)
   uint32_t walk_min4 = 16;                // the same threshold for the four-wide walk (PTAMD_WALK_MIN4; 1/4/8/16/24: 813/902/960/994/971 Msamples/s)
   uint32_t tiles_per_ticket = 1;
 };
@@ -302,9 +302,10 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     size_t launch_lds = lds;
     if (restart && !resident) {
       const uint32_t need = 3u * s.depth4 + 1u;
-      const uint32_t waves = restart_threads() / 64u;
+      const uint32_t waves = restart_threads(false) / 64u;
       const uint32_t share = 160u * 1024u / restart_wide_blocks_per_cu() - 256u;   // LDS bytes of one resident workgroup
-      // the top of the tree (breadth-first numbering: nodes 0..340 are its first five levels when full) goes to LDS too
+      // the top of the tree (breadth-first numbering: nodes 0..340 are its first five levels when full) goes to LDS too:
+      // 640 nodes = 80 KB of the one workgroup's 160 KB, the rest holds 9 stack entries per lane
       uint32_t treelet = ctx->treelet_nodes < s.n_nodes4 ? ctx->treelet_nodes : s.n_nodes4;
       if (treelet * 128u + waves * 512u * 4u > share) treelet = (share - waves * 512u * 4u) / 128u;   // keep >= 4 stack entries
       uint32_t fit = (share - treelet * 128u) / (waves * 512u);
@@ -325,7 +326,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     }
     const int bpc = occ.blocks_per_cu;
     // waves that take tile tickets: every wave of a persistent block, the shader waves of a split block
-    const uint32_t waves_per_block = split ? split_shader_waves() : (restart ? restart_threads() / 64u : kPersistentThreads / 64u);
+    const uint32_t waves_per_block = split ? split_shader_waves() : (restart ? restart_threads(resident) / 64u : kPersistentThreads / 64u);
     uint32_t n_blocks = (uint32_t)ctx->n_cus * (uint32_t)bpc;
     p.sample_count = count;
     p.frame_nb0 = l->frame_nb;
