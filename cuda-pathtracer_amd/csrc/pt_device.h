@@ -239,6 +239,7 @@ struct KParams {
   float* samples_out;
   // restart kernel: per-wave pools of fresh paths (192 float4 per wave) and the straggler threshold of a round
   float4* pool;
+  uint32_t pool_lds_offset;   // != 0: the pools live in LDS this many bytes behind the start of the dynamic LDS (2 304 bytes per wave)
   uint32_t round_min, round_div;
   uint32_t walk_min;   // a box phase ends once fewer lanes than this are still walking (1: when none is)
   // four-wide walk (scenes that do not fit in LDS): 8 float4 per node, per-lane stacks in LDS with a global continuation

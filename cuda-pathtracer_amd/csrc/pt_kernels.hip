@@ -57,7 +57,7 @@ namespace ptamd {
 #define PT_PERSISTENT_THREADS 512
 #endif
 #ifndef PT_RS_THREADS
-#define PT_RS_THREADS 512
+#define PT_RS_THREADS 768   /* two workgroups of 12 waves per CU: two scene copies leave room for the waves' pools in LDS */
 #endif
 #ifndef PT_RS_WAVES_PER_EU
 #define PT_RS_WAVES_PER_EU 6
@@ -965,6 +965,28 @@ PT_DEV void pool_store(float4* slab, uint32_t e, const Path& st)
   slab[128u + e] = make_float4(u_as_f(st.rng.v2), u_as_f(st.rng.v3), u_as_f(st.rng.v4), u_as_f(st.rng.d));
 }
 
+// The same pool in LDS, when the workgroup's share has room next to the staged scene (2 304 bytes per wave): 9 dwords
+// per path, one 64-dword plane each (a wave's stores and a run of restarting lanes' loads are conflict-free).  Of the
+// XORWOW state only v2, v3, v4 are kept: path_begin draws exactly twice (camera_dof), after which v0 and v1 are the
+// generator's seed-independent initial v2 and v3, and the Weyl counter follows from v2 (= initial v4 = 5783321 + t0).
+PT_DEV void pool_store_lds(uint32_t* pool, uint32_t e, const Path& st)
+{
+  pool[e] = f_as_u(st.o.x); pool[64u + e] = f_as_u(st.o.y); pool[128u + e] = f_as_u(st.o.z);
+  pool[192u + e] = f_as_u(st.d.x); pool[256u + e] = f_as_u(st.d.y); pool[320u + e] = f_as_u(st.d.z);
+  pool[384u + e] = st.rng.v2; pool[448u + e] = st.rng.v3; pool[512u + e] = st.rng.v4;
+}
+
+PT_DEV void pool_load_lds(const uint32_t* pool, uint32_t e, Path& st)
+{
+  st.o = mk3(u_as_f(pool[e]), u_as_f(pool[64u + e]), u_as_f(pool[128u + e]));
+  st.d = mk3(u_as_f(pool[192u + e]), u_as_f(pool[256u + e]), u_as_f(pool[320u + e]));
+  st.rng.v2 = pool[384u + e]; st.rng.v3 = pool[448u + e]; st.rng.v4 = pool[512u + e];
+  const uint32_t t1 = 2591861531u * 0xf7dcefddu;          // xorwow_init: seed-independent half of the scramble
+  st.rng.v0 = 521288629u + t1;
+  st.rng.v1 = 88675123u ^ t1;
+  st.rng.d = 6615241u + t1 + (st.rng.v2 - 5783321u) + 2u * 362437u;
+}
+
 PT_DEV void pool_load(const float4* slab, uint32_t e, Path& st)
 {
   // the slab is rewritten by this wave for every tile: read past the CU's vector L1 (it is write-through and may hold
@@ -1195,6 +1217,8 @@ pt_megakernel_restart(const KParams p)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t gwave = blockIdx.x * (THREADS / 64u) + (threadIdx.x >> 6);
   float4* slab = p.pool + (size_t)gwave * 192u;
+  // p.pool_lds_offset != 0: the pools live in LDS behind the staged scene (576 dwords per wave) instead of the global slab
+  uint32_t* lds_pool = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_mem) + p.pool_lds_offset) + (threadIdx.x >> 6) * 576u;
   Stack4 stk;
   stk.top = s_mem;
   stk.top_n = WIDE ? p.treelet_nodes : 0u;
@@ -1274,9 +1298,11 @@ pt_megakernel_restart(const KParams p)
           if (x < p.width && y < p.y_limit) {
             Path fresh;
             path_begin(p, x, y, fresh, tile_k);
-            pool_store(slab, lane, fresh);
+            if (p.pool_lds_offset) pool_store_lds(lds_pool, lane, fresh);
+            else pool_store(slab, lane, fresh);
           }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have reached L2 before any lane reads them back
+          // the stores have reached L2 (LDS: are ordered before this wave's later reads) before any lane reads them back
+          if (!p.pool_lds_offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         pool_rd = 0u;
       }
@@ -1286,7 +1312,8 @@ pt_megakernel_restart(const KParams p)
         const uint32_t e = pool_rd + rank;
         const uint32_t x = tile_x0 + (e & (PT_TILE_W - 1u)), y = tile_y0 + (e >> PT_TILE_W_LOG2);
         if (x < p.width && y < p.y_limit) {   // entries of pixels outside the frame were never written: skip them
-          pool_load(slab, e, st);
+          if (p.pool_lds_offset) pool_load_lds(lds_pool, e, st);
+          else pool_load(slab, e, st);
           st.throughput = mk3(1.0f);
           st.acc = mk3(0.0f);
           st.specular_col = 0.0f;

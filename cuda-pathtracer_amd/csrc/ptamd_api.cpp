@@ -77,7 +77,8 @@ struct ptamd_context {
   // measured (scripts/gpu_r2_sweep.sh, 1080p x 4 spp x 4 bounces): round_min 16-32 and walk_min 4-6 are a flat optimum
   uint32_t round_min = 16, round_div = 4; // PTAMD_ROUND_MIN, PTAMD_ROUND_DIV
   uint32_t walk_min = 5;                  // restart kernel: a box phase ends once fewer lanes than this still walk (PTAMD_WALK_MIN)
-  uint32_t treelet_nodes = 640;           // wide walk: nodes of the top of the tree staged in LDS (PTAMD_TREELET; 341 / 700 / 1000: 1268 / 1278 / 1226)
+  bool pool_in_lds = true;                // restart kernel: pools of fresh paths in LDS when they fit (PTAMD_POOL_LDS=0: always the global slab)
+  uint32_t treelet_nodes = 512;           // wide walk: nodes of the top of the tree staged in LDS (PTAMD_TREELET; with LDS pools 341 / 512 / 640: 1286 / 1291 / 1275)
   uint32_t walk_min4 = 16;                // the same threshold for the four-wide walk (PTAMD_WALK_MIN4; 1/4/8/16/24: 813/902/960/994/971 Msamples/s)
   uint32_t tiles_per_ticket = 1;
 };
@@ -305,18 +306,33 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       const uint32_t waves = restart_threads(false) / 64u;
       const uint32_t share = 160u * 1024u / restart_wide_blocks_per_cu() - 256u;   // LDS bytes of one resident workgroup
       // the top of the tree (breadth-first numbering: nodes 0..340 are its first five levels when full) goes to LDS too:
-      // 640 nodes = 80 KB of the one workgroup's 160 KB, the rest holds 9 stack entries per lane
+      // 512 nodes = 64 KB of the one workgroup's 160 KB, then 7 stack entries per lane
+      // ... and the waves' pools of fresh paths (2 304 bytes each), behind the stacks
+      const uint32_t pools = ctx->pool_in_lds ? waves * 2304u : 0u;
       uint32_t treelet = ctx->treelet_nodes < s.n_nodes4 ? ctx->treelet_nodes : s.n_nodes4;
-      if (treelet * 128u + waves * 512u * 4u > share) treelet = (share - waves * 512u * 4u) / 128u;   // keep >= 4 stack entries
-      uint32_t fit = (share - treelet * 128u) / (waves * 512u);
+      if (treelet * 128u + waves * 512u * 4u + pools > share) treelet = (share - pools - waves * 512u * 4u) / 128u;   // keep >= 4 stack entries
+      uint32_t fit = (share - pools - treelet * 128u) / (waves * 512u);
       if (const char* ev = std::getenv("PTAMD_STACK_LDS")) { int v = std::atoi(ev); if (v >= 1 && (uint32_t)v <= fit) fit = (uint32_t)v; }   // tuning knob
       p.treelet_nodes = treelet;
       p.stack_lds_entries = need < fit ? need : fit;
       p.stack_spill_entries = need - p.stack_lds_entries;
       launch_lds = (size_t)treelet * 128u + (size_t)p.stack_lds_entries * waves * 512u;
+      if (pools) { p.pool_lds_offset = (uint32_t)launch_lds; if (!p.pool_lds_offset) p.pool_lds_offset = 16u; launch_lds = p.pool_lds_offset + pools; }
+    }
+    if (restart && resident) {
+      // pools of fresh paths in LDS when two workgroups with their scene copies leave room for them (2 304 bytes per
+      // wave); else in a global slab (3 KiB per wave, L2-resident)
+      const uint32_t waves = restart_threads(true) / 64u;
+      const size_t with_pools = ((lds + 15u) & ~(size_t)15u) + (size_t)waves * 2304u;
+      const size_t blocks_wanted = (24u + waves - 1u) / waves;             // 24 waves per CU
+      if (ctx->pool_in_lds && with_pools * blocks_wanted + 1024u <= 160u * 1024u) {
+        p.pool_lds_offset = (uint32_t)((lds + 15u) & ~(size_t)15u);
+        if (p.pool_lds_offset == 0) p.pool_lds_offset = 16u;               // (an empty scene: keep the flag non-zero)
+        launch_lds = p.pool_lds_offset + (size_t)waves * 2304u;
+      }
     }
     ptamd_context::Occupancy& occ = ctx->occupancy[split ? 2 : (restart ? 3 : 0)];
-    const size_t occ_key = resident ? lds : (restart ? launch_lds + 1u : 0);
+    const size_t occ_key = resident ? (restart ? launch_lds : lds) : (restart ? launch_lds + 1u : 0);
     if (occ.blocks_per_cu < 0 || occ.lds != occ_key) {
       int q = -1;
       e = split ? split_blocks_per_cu(resident, lds, &q)
@@ -346,7 +362,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     const bool parks = count > 1 || restart;
     if (parks) {
       const size_t sample_bytes = ((size_t)count * rows * l->width * 3u * sizeof(float) + 255u) & ~(size_t)255u;
-      const size_t pool_bytes = restart ? (size_t)n_blocks * waves_per_block * 192u * sizeof(float4) : 0u;
+      const size_t pool_bytes = (restart && !p.pool_lds_offset) ? (size_t)n_blocks * waves_per_block * 192u * sizeof(float4) : 0u;
       const size_t spill_bytes = (size_t)n_blocks * waves_per_block * p.stack_spill_entries * 512u;
       const size_t need = sample_bytes + pool_bytes + spill_bytes + 16u;
       ptamd_context::SampleScratch* sc = nullptr;
@@ -471,6 +487,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
     int v = std::atoi(e);
     ctx->walk_min4 = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
+  if (const char* e = std::getenv("PTAMD_POOL_LDS")) ctx->pool_in_lds = std::atoi(e) != 0; // tuning knob
   if (const char* e = std::getenv("PTAMD_TREELET")) { // tuning knob
     int v = std::atoi(e);
     ctx->treelet_nodes = (uint32_t)(v < 0 ? 0 : (v > 1024 ? 1024 : v));
