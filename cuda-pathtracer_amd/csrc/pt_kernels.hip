@@ -443,11 +443,17 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
   hit.normal = surface_normal;
   hit.light = -1;
   hit.ior = s4.w;
-  TexDesc tex;
-  tex.w = (int32_t)f_as_u(s5.x); tex.h = (int32_t)f_as_u(s5.y); tex.nb_chan = (int32_t)f_as_u(s5.z); tex.pad = 0; tex.offset = f_as_u(s5.w);
-  const float* texel = p.texels + tex.offset + texture_idx(tex, uvx, uvy);
-  hit.diffuse_col = mk3(texel[0], texel[1], texel[2]);
-  hit.specular_col = texel[3];
+  if (f_as_u(s4.z) & 0x80000000u) {
+    // 1x1 diffuse+specular map: the record carries its only texel (ptamd_api.cpp) — no dependent load
+    hit.diffuse_col = mk3(s5.x, s5.y, s5.z);
+    hit.specular_col = s5.w;
+  } else {
+    TexDesc tex;
+    tex.w = (int32_t)f_as_u(s5.x); tex.h = (int32_t)f_as_u(s5.y); tex.nb_chan = (int32_t)f_as_u(s5.z); tex.pad = 0; tex.offset = f_as_u(s5.w);
+    const float* texel = p.texels + tex.offset + texture_idx(tex, uvx, uvy);
+    hit.diffuse_col = mk3(texel[0], texel[1], texel[2]);
+    hit.specular_col = texel[3];
+  }
   if (STATS) cnt.mesh_hits++;
   if (f_as_u(s6.x) != 0u) {
     TexDesc nt;

@@ -562,7 +562,8 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
     std::memcpy(&t[9], &i, 4);
     // self-contained shading record (one parallel burst of loads per hit instead of the dependent
     // face -> material -> texture descriptor -> texel chain of intersection.cuh:216-243): 28 floats =
-    // n0 n1 n2 | uv0 uv1 uv2 | tangent | material id | ior | diffuse+spec map {w,h,nb_chan,offset} | normal map {..} (w = 0: none)
+    // n0 n1 n2 | uv0 uv1 uv2 | tangent | material id (sign bit: constant map) | ior | diffuse+spec map {w,h,nb_chan,offset}
+    // or its one RGBA texel | normal map {..} (w = 0: none)
     float* s = &shade[(size_t)i * kShadeFloats];
     std::memcpy(s, f.normals, 36);
     std::memcpy(s + 9, f.texcoords, 24);
@@ -571,8 +572,17 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
     const ptamd_material& m = sc->materials[f.material_id];
     std::memcpy(s + 19, &m.ior, 4);
     const ptamd_texture_desc& dt = sc->textures[m.diffuse_spec_map];
-    const int32_t d4[4] = { dt.w, dt.h, dt.nb_chan, (int32_t)(uint32_t)dt.offset };
-    std::memcpy(s + 20, d4, 16);
+    if (dt.w == 1 && dt.h == 1) {
+      // a 1x1 diffuse+specular map (every material of indoor.obj as the reference loads it on Linux): sampleTexture can
+      // only ever return texel 0 (intersection.cuh:20-26: x = int(uv.x * 0)), so the record carries the texel itself
+      // and the kernel skips the dependent texel load; flagged in the sign bit of the material id word
+      std::memcpy(s + 20, sc->texels + dt.offset, 16);
+      const uint32_t flagged = f.material_id | 0x80000000u;
+      std::memcpy(s + 18, &flagged, 4);
+    } else {
+      const int32_t d4[4] = { dt.w, dt.h, dt.nb_chan, (int32_t)(uint32_t)dt.offset };
+      std::memcpy(s + 20, d4, 16);
+    }
     if (m.normal_map >= 0) {
       const ptamd_texture_desc& nt = sc->textures[m.normal_map];
       const int32_t n4[4] = { nt.w, nt.h, nt.nb_chan, (int32_t)(uint32_t)nt.offset };
