@@ -428,9 +428,10 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
     hit.normal = normalize(mk3(la.w, lb.x, lb.y) - (n.t * d)); // intersection.cuh:208: origin ignored
     return hit.dist < PT_MAX_DIST;
   }
-  // one burst of seven independent 16-byte loads: geometry, material and both texture descriptors of the face
+  // one burst of six independent 16-byte loads: geometry, material and the diffuse+specular map of the face (the
+  // normal map's descriptor follows only for normal-mapped materials)
   const float4* sh = p.shade + (size_t)n.idx * 7;
-  const float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3], s4 = sh[4], s5 = sh[5], s6 = sh[6];
+  const float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3], s4 = sh[4], s5 = sh[5];
   const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
   const float u = n.u, v = n.v;
   const float w = 1.0f - u - v;
@@ -455,7 +456,8 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
     hit.specular_col = texel[3];
   }
   if (STATS) cnt.mesh_hits++;
-  if (f_as_u(s6.x) != 0u) {
+  if (f_as_u(s4.z) & 0x40000000u) {   // normal-mapped material (flag set at upload): its descriptor is the record's 7th float4
+    const float4 s6 = sh[6];
     TexDesc nt;
     nt.w = (int32_t)f_as_u(s6.x); nt.h = (int32_t)f_as_u(s6.y); nt.nb_chan = (int32_t)f_as_u(s6.z); nt.pad = 0; nt.offset = f_as_u(s6.w);
     const float* nx = p.texels + nt.offset + texture_idx(nt, uvx, uvy);

@@ -587,6 +587,10 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
       const ptamd_texture_desc& nt = sc->textures[m.normal_map];
       const int32_t n4[4] = { nt.w, nt.h, nt.nb_chan, (int32_t)(uint32_t)nt.offset };
       std::memcpy(s + 24, n4, 16);
+      uint32_t word;
+      std::memcpy(&word, s + 18, 4);
+      word |= 0x40000000u;               // bit 30 of the material id word: the record's 7th float4 (normal map) is in use
+      std::memcpy(s + 18, &word, 4);
     }
   }
   std::vector<int32_t> mats((size_t)sc->n_materials * 4, 0);
