@@ -121,11 +121,12 @@ GPU_WORKER = textwrap.dedent("""
     bg = P.BandGather(H, W, world, rank, torch.device("cpu"))
     bgi = P.BandGather(H, W, world, rank, torch.device("cpu"), interleave=16)
     y0, y1 = bg.bands[rank]
+    can_batch = os.environ.get("PTAMD_DEFAULT_KERNEL", "6") in ("3", "5", "6")   # (a pinned tile kernel renders frame by frame)
     with P.Context(0) as ctx:                                  # both ranks share the box's one GPU
         ctx.setup_function_tables()
         sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(cube)
         fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=(y0, y1), band_local=True, machine_share=3)
-        fr.render(spp=spp, bounces=B, batched=True)
+        fr.render(spp=spp, bounces=B, batched=can_batch)
         # interleaved bands are a feature of the default (restart) kernel: under a pinned PTAMD_DEFAULT_KERNEL knob the
         # second gather repeats the contiguous one
         ilv_ok = os.environ.get("PTAMD_DEFAULT_KERNEL", "6") == "6"

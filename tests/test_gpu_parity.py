@@ -331,6 +331,24 @@ def test_wide_walk_with_a_spilling_stack(P, O, gpu_ctx, monkeypatch):
     assert_same(acc, rgba, *ref, "wide walk, stack in LDS")
 
 
+def test_scene_that_fills_the_lds_share_keeps_its_pools_in_global_memory(P, O, gpu_ctx):
+    """An LDS-resident scene of 53-64 KB leaves no room for the restart kernel's path pools next to two scene copies: they
+    go to the global slab instead (ptamd_api.cpp); same pixels either way."""
+    rng = np.random.default_rng(77)
+    soup = random_soup(rng, 400, extent=2.0, size=0.35)
+    for n in range(280, 400, 10):                       # the first size whose nodes + triangles land in the window
+        hs = make_scene(P, soup[:n], lights=[((0.0, 2.5, 1.0), (1, 1, 1), 5.0, 0.6)])
+        info = gpu_ctx.scene_info(gpu_ctx.upload_scene(hs))
+        if 53 * 1024 < info["lds_bytes_bvh"] <= 64 * 1024:
+            break
+    cube = synthetic_cubemap(rng, 2)
+    assert 53 * 1024 < info["lds_bytes_bvh"] <= 64 * 1024 and info["n_nodes"] <= 896, info
+    ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 96, 64, spp=3, bounces=4)
+    for k in (P.KERNEL_BVH_RESTART, P.KERNEL_BVH_PERSISTENT, P.KERNEL_BVH):
+        acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 96, 64, 3, 4, k)
+        assert_same(acc, rgba, *ref, f"LDS-filling scene kernel {k}")
+
+
 def test_large_scene_uses_global_memory_variant(P, O, gpu_ctx):
     """A scene whose traversal set exceeds the LDS budget renders through the L2-resident path."""
     rng = np.random.default_rng(33)
