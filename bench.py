@@ -2,7 +2,7 @@
 """bench.py — headline benchmark: Msamples/s (and ms/frame) at 1920x1080, 4 spp, indoor.obj (BASELINE.json configs[1]).
 
 One "step" = one frame of the hot path = `spp` static frames of the megakernel (frame seeds 1..spp) accumulating into
-a zeroed temporal framebuffer, with every input resident in HBM before the timed region starts.  1 sample = one
+a temporal framebuffer that starts from zero (ptamd_launch.reset_accumulation), with every input resident in HBM before the timed region starts.  1 sample = one
 execution of the reference kernel() for one pixel.
 
     python bench.py --gpus N --steps K --warmup W
@@ -14,7 +14,7 @@ into pixel-row bands (cuda_pathtracer_amd.tiles), each rank renders its band wit
 finished RGBA8 bands are gathered with one RCCL all-gather per frame.  The frame is fixed, so scaling is "strong".
 
 The headline (`value`) issues the spp frames of a step as ONE batched launch (ptamd_launch.frame_count: same
-accumulator and surface as spp consecutive launches, bit for bit) and keeps two (one GPU) or three (several GPUs) steps
+accumulator and surface as spp consecutive launches, bit for bit) and keeps two (one GPU) or four (several GPUs) steps
 in flight on separate HIP streams, each launch sized to its share of the GPU, so that a step's ramp, tail, resolve pass
 and all-gather overlap the bulk of the next one.  Next to it, at N = 1, the line reports
   value_unpipelined  the same batched launch, one at a time (frames_in_flight = 1): `ms_per_frame` is its latency;
@@ -44,8 +44,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # HIP maps streams onto 4 hardware queues by default; two frames-in-flight streams sharing a queue would serialise
-# (measured: -30 %).  Frames + the RCCL stream + torch's own streams need more than 4: ask for 8 before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (measured: -30 %; with 8 queues five frame streams collapse the same way, with 16 they do not).  Frames + RCCL's
+# streams + torch's own need more than 4: ask for 16 before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 4, 4
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
@@ -72,8 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate HIP streams, each with its own buffers (double "
                          "buffering, as the reference double-buffers its GL renderbuffers: driver/interop.cpp:107-111).  "
-                         "0 = auto: 2 on one GPU, 3 on several GPUs (the RCCL all-gather of frame i overlaps the render of "
-                         "frames i+1, i+2); each launch is sized to 1/n of the GPU (ptamd_launch.machine_share)")
+                         "0 = auto: 2 on one GPU, 4 on several GPUs (the RCCL all-gather of frame i overlaps the render of "
+                         "the next ones); each launch is sized to 1/n of the GPU (ptamd_launch.machine_share)")
     ap.add_argument("--no-share", dest="share", action="store_false",
                     help="with several frames in flight, size every launch to the whole GPU instead of its 1/n share")
     ap.add_argument("--sequential", action="store_true", help="one launch per spp instead of one batched launch per frame")
@@ -205,8 +206,6 @@ class Workload:
         self.info = self.ctx.scene_info(self.sid)
         self.slots = []
         for i in range(n_slots):
-            fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(self.y0, self.y1),
-                                 band_local=True, machine_share=n_slots if (share and n_slots > 1) else 0, interleave=interleave)
             # (a proxy band is gathered as if it were the whole frame: same message size as the rank's real gather share)
             if not gather:
                 bg = None
@@ -214,6 +213,10 @@ class Workload:
                 bg = P.BandGather(self.my_rows, W, 1, 0, self.dev)
             else:
                 bg = P.BandGather(H, W, world, rank, self.dev, interleave=interleave[2] if interleave is not None else 0)
+            # the renderer writes its rows straight into the collective's send buffer: no staging copy per frame
+            fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(self.y0, self.y1),
+                                 band_local=True, machine_share=n_slots if (share and n_slots > 1) else 0, interleave=interleave,
+                                 surface=bg.send_rows() if bg is not None else None)
             st = torch.cuda.current_stream() if n_slots == 1 else torch.cuda.Stream(device=self.dev)
             self.slots.append((fr, bg, st))
         self.counter = 0
@@ -227,10 +230,11 @@ class Workload:
         fr, bg, st = self.slots[self.counter % self.n_slots]
         self.counter += 1
         with torch.cuda.stream(st):
-            fr.accum.zero_()
             if ev is not None:
                 ev[0].record(st)
-            fr.render(spp=self.spp, bounces=self.B, kernel=self.kernel, stream=st, batched=self.batched)
+            # reset=True: every step starts a new accumulation (the same result as clearing the accumulator first, which
+            # tests/test_gpu_parity.py asserts; the clear is folded into the launch that would read it)
+            fr.render(spp=self.spp, bounces=self.B, kernel=self.kernel, stream=st, batched=self.batched, reset=True)
             if ev is not None:
                 ev[1].record(st)
             if bg is not None:
@@ -341,7 +345,8 @@ def main():
     if args.aperture is not None:
         hs.camera["aperture"] = args.aperture
     cube = P.cubemap_for_scene(hs)
-    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (3 if world > 1 else 2)
+    # measured on one rank's share of an 8-way split (scripts/band_proxy.py): 3 / 4 / 5 frames in flight = 0.166 / 0.155 / 0.183 ms
+    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (4 if (world > 1 or args.as_rank is not None) else 2)
     gather = world > 1 or force_gather
 
     rows = None

@@ -220,6 +220,7 @@ struct KParams {
   float* tfb;         // float3 per pixel
   uint32_t* surface;  // RGBA8 per pixel
   uint32_t tfb_row0;  // buffers hold frame rows starting here (0 for full-frame buffers)
+  uint32_t tfb_reset; // != 0: treat the accumulator as zero on entry (ptamd_launch.reset_accumulation)
   uint32_t surf_row0;
   unsigned long long* stats; // 8 counters or nullptr
   unsigned long long* error_flag; // incremented when a bounded spin of the split kernel times out

@@ -725,7 +725,7 @@ PT_DEV void path_finish(const KParams& p, const Path& st)
   // row-flipped accumulator index (raytrace.cu:252)
   const size_t i = (size_t)(p.height - y - 1u - p.tfb_row0) * p.width + x;
   float* tp = p.tfb + i * 3;
-  f3 t = mk3(tp[0], tp[1], tp[2]);
+  f3 t = p.tfb_reset ? mk3(0.0f) : mk3(tp[0], tp[1], tp[2]);   // tfb_reset: the accumulator counts as freshly zeroed
   t = t * (float)p.is_static;
   t = t + rad;
   tp[0] = t.x; tp[1] = t.y; tp[2] = t.z;
@@ -1718,13 +1718,16 @@ __global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakern
 // frame number (the intermediate surfaces of frames 0..count-2 would be overwritten anyway).
 __global__ void __launch_bounds__(256) pt_resolve_kernel(const KParams p)
 {
+  // the ticket heads of this launch are spent (the megakernel has finished: stream order): leave them zeroed for the
+  // launch that gets this slot of the ring next, instead of a memset in front of every launch
+  if (blockIdx.x == 0 && threadIdx.x < 8u && p.tile_heads) p.tile_heads[threadIdx.x * PT_HEAD_STRIDE] = 0u;
   const uint32_t rows = p.row_end - p.row_begin;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= rows * p.width) return;
   const uint32_t x = i % p.width, y = p.row_begin + i / p.width;
   const size_t ti = (size_t)(p.height - y - 1u - p.tfb_row0) * p.width + x;
   float* tp = p.tfb + ti * 3;
-  f3 t = mk3(tp[0], tp[1], tp[2]);
+  f3 t = p.tfb_reset ? mk3(0.0f) : mk3(tp[0], tp[1], tp[2]);   // tfb_reset: the accumulator counts as freshly zeroed
   for (uint32_t k = 0; k < p.sample_count; ++k) {
     const float* sp = p.samples_out + (((size_t)k * rows + (y - p.row_begin)) * p.width + x) * 3;
     t = t * (float)p.is_static;
@@ -1745,6 +1748,9 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel(const KParams p)
 // accumulator and in every sample plane, the four RGBA8 results one uint4.  Per-pixel arithmetic is unchanged.
 __global__ void __launch_bounds__(256) pt_resolve_kernel4(const KParams p)
 {
+  // the ticket heads of this launch are spent (the megakernel has finished: stream order): leave them zeroed for the
+  // launch that gets this slot of the ring next, instead of a memset in front of every launch
+  if (blockIdx.x == 0 && threadIdx.x < 8u && p.tile_heads) p.tile_heads[threadIdx.x * PT_HEAD_STRIDE] = 0u;
   const uint32_t rows = p.row_end - p.row_begin;
   const uint32_t groups_per_row = p.width / 4u;
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
@@ -1752,7 +1758,8 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel4(const KParams p)
   const uint32_t x0 = (g % groups_per_row) * 4u, y = p.row_begin + g / groups_per_row;
   const size_t ti = (size_t)(p.height - y - 1u - p.tfb_row0) * p.width + x0;
   float4* tp = reinterpret_cast<float4*>(p.tfb + ti * 3);
-  float4 a = tp[0], b = tp[1], c = tp[2];
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+  if (!p.tfb_reset) { a = tp[0]; b = tp[1]; c = tp[2]; }   // tfb_reset: the accumulator counts as freshly zeroed
   float t[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
   const float is_static = (float)p.is_static;
   for (uint32_t k = 0; k < p.sample_count; ++k) {

@@ -62,6 +62,7 @@ struct ptamd_context {
   uint32_t* d_tickets = nullptr;
   uint32_t* d_heads = nullptr;   // kTicketRing sets of 8 ticket heads, PT_HEAD_STRIDE dwords apart (persistent kernel)
   uint32_t ticket_next = 0;
+  std::vector<bool> heads_clean;   // per ring slot: its ticket heads are known to be zero (creation, or its last user's resolve pass)
   int n_cus = 0;
   // resident workgroups per CU of the persistent kernels: depends on the scene's dynamic LDS bytes, so the cache is
   // keyed by them ([0] persistent, [1] blockwise, [2] split, [3] restart)
@@ -209,6 +210,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   p.bounces = (int32_t)l->bounces;
   p.post_id = l->post_id;
   p.tfb = l->temporal_framebuffer;
+  p.tfb_reset = l->reset_accumulation ? 1u : 0u;
   p.surface = static_cast<uint32_t*>(l->surface_rgba8);
   if (l->band_local_buffers) {
     p.tfb_row0 = l->height - l->row_end; // band covers accumulator rows [H-row_end, H-row_begin)
@@ -243,6 +245,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     for (uint32_t k = 0; k < l->frame_count; ++k) {
       ptamd_launch one = *l;
       one.frame_nb = l->frame_nb + k; one.frame_count = 1; one.kernel = PTAMD_KERNEL_BRUTE_FORCE;
+      if (k > 0) one.reset_accumulation = 0;
       rc = do_launch(ctx, &one, stats);
       if (rc != PTAMD_OK) return rc;
     }
@@ -402,12 +405,18 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     if (split) PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)p.n_static, 1, stream));
     if (!split) {
       p.tile_heads = ctx->d_heads + (size_t)slot * 8u * PT_HEAD_STRIDE;
-      PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_heads), 0, 8u * PT_HEAD_STRIDE, stream));
+      // the whole ring is zeroed at creation and a launch that parks its samples has its resolve pass zero its heads
+      // again (pt_resolve_kernel); only slots whose last user did not get that far are cleared here
+      if (!ctx->heads_clean[slot]) PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_heads), 0, 8u * PT_HEAD_STRIDE, stream));
+      ctx->heads_clean[slot] = false;
     }
     if (split) { p.tiles_per_ticket = 1; e = launch_megakernel_split(p, resident, lds, stats, n_blocks, stream); }
     else if (restart) e = launch_megakernel_restart(p, resident, launch_lds, stats, n_blocks, stream);
     else e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
-    if (e == hipSuccess && parks) e = launch_resolve(p, stream);
+    if (e == hipSuccess && parks) {
+      e = launch_resolve(p, stream);
+      if (e == hipSuccess && !split) ctx->heads_clean[slot] = true;
+    }
   } else {
     e = launch_megakernel(p, kind, resident, lds, stats, stream);
   }
@@ -464,6 +473,8 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   PT_HIP(hipMemset(ctx->d_stats, 0, 16 * sizeof(unsigned long long)));
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), kTicketRing * sizeof(uint32_t)));
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_heads), (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
+  PT_HIP(hipMemset(ctx->d_heads, 0, (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
+  ctx->heads_clean.assign(kTicketRing, true);
   hipDeviceProp_t prop;
   PT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   ctx->n_cus = prop.multiProcessorCount;

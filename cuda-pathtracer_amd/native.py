@@ -71,7 +71,8 @@ class Launch(C.Structure):
                 ("frame_nb", C.c_uint32), ("bounces", C.c_uint32), ("moved", C.c_int32), ("post_id", C.c_uint32),
                 ("kernel", C.c_uint32), ("band_local_buffers", C.c_uint32), ("frame_count", C.c_uint32),
                 ("machine_share", C.c_uint32),
-                ("interleave_ranks", C.c_uint32), ("interleave_rank", C.c_uint32), ("interleave_rows", C.c_uint32)]
+                ("interleave_ranks", C.c_uint32), ("interleave_rank", C.c_uint32), ("interleave_rows", C.c_uint32),
+                ("reset_accumulation", C.c_uint32)]
 
 
 class TraceStats(C.Structure):

@@ -117,7 +117,7 @@ class Context:
                     moved: bool = False, post_id: int = POST_NONE, stream=None,
                     rows: Optional[tuple] = None, kernel: int = N.KERNEL_AUTO,
                     band_local_buffers: bool = False, frame_count: int = 1, machine_share: int = 0,
-                    interleave: Optional[tuple] = None) -> N.Launch:
+                    interleave: Optional[tuple] = None, reset_accumulation: bool = False) -> N.Launch:
         """interleave = (ranks, rank, band_rows): render the interleaved bands of `rank` (ptamd_launch.interleave_*)."""
         l = N.Launch()
         l.surface_rgba8 = _ptr(array)
@@ -134,6 +134,7 @@ class Context:
         l.machine_share = machine_share
         if interleave is not None:
             l.interleave_ranks, l.interleave_rank, l.interleave_rows = interleave
+        l.reset_accumulation = 1 if reset_accumulation else 0
         return l
 
     def raytrace_ex(self, launch: N.Launch) -> None:
@@ -202,9 +203,11 @@ class FrameRenderer:
 
     def __init__(self, ctx: Context, scene_id: int, cubemap_id: int, cam: N.Camera, width: int, height: int,
                  rows: Optional[tuple] = None, band_local: bool = False, machine_share: int = 0,
-                 interleave: Optional[tuple] = None):
+                 interleave: Optional[tuple] = None, surface=None):
         """interleave = (ranks, rank, band_rows): this renderer owns the interleaved bands of `rank` (band j of the frame
-        belongs to rank j % ranks); its buffers hold those bands one after the other."""
+        belongs to rank j % ranks); its buffers hold those bands one after the other.
+        surface: render into this uint8[rows, width, 4] device tensor instead of allocating one (e.g. the send buffer
+        of a BandGather: no staging copy per frame)."""
         import torch
         self.ctx, self.scene_id, self.cubemap_id, self.cam = ctx, scene_id, cubemap_id, cam
         self.width, self.height = width, height
@@ -219,7 +222,12 @@ class FrameRenderer:
         if interleave is not None:
             n_rows = interleaved_rows(height, *interleave)
         dev = torch.device("cuda", ctx.device)
-        self.surface = torch.zeros((n_rows, width, 4), dtype=torch.uint8, device=dev)
+        if surface is not None:
+            if tuple(surface.shape) != (n_rows, width, 4) or surface.dtype != torch.uint8 or not surface.is_contiguous():
+                raise ValueError(f"surface must be a contiguous uint8[{n_rows}, {width}, 4] tensor")
+            self.surface = surface
+        else:
+            self.surface = torch.zeros((n_rows, width, 4), dtype=torch.uint8, device=dev)
         self.accum = torch.zeros((n_rows, width, 3), dtype=torch.float32, device=dev)
 
     def reset(self) -> None:
@@ -227,15 +235,18 @@ class FrameRenderer:
         self.surface.zero_()
 
     def render(self, spp: int, bounces: int = REFERENCE_BOUNCES, post_id: int = POST_NONE,
-               kernel: int = N.KERNEL_AUTO, stream=None, first_frame: int = 1, batched: bool = False) -> None:
+               kernel: int = N.KERNEL_AUTO, stream=None, first_frame: int = 1, batched: bool = False,
+               reset: bool = False) -> None:
         """`batched=True` issues the spp frames as ONE launch (ptamd_launch.frame_count): same
-        accumulator and final surface bit for bit, no kernel tails between frames."""
+        accumulator and final surface bit for bit, no kernel tails between frames.  `reset=True` starts a new
+        accumulation: the first launch treats the accumulator as zero (ptamd_launch.reset_accumulation) — the same
+        result as clearing it first."""
         if batched and spp > 1:
             l = self.ctx.make_launch(self.surface, self.accum, self.scene_id, self.cubemap_id, self.cam,
                                      self.width, self.height, frame_nb=first_frame, bounces=bounces, post_id=post_id,
                                      stream=stream, rows=self.rows, kernel=kernel,
                                      band_local_buffers=self.band_local, frame_count=spp, machine_share=self.machine_share,
-                                     interleave=self.interleave)
+                                     interleave=self.interleave, reset_accumulation=reset)
             self.ctx.raytrace_ex(l)
             return
         for k in range(first_frame, first_frame + spp):
@@ -243,5 +254,5 @@ class FrameRenderer:
                                      self.width, self.height, frame_nb=k, bounces=bounces, post_id=post_id,
                                      stream=stream, rows=self.rows, kernel=kernel,
                                      band_local_buffers=self.band_local, machine_share=self.machine_share,
-                                     interleave=self.interleave)
+                                     interleave=self.interleave, reset_accumulation=reset and k == first_frame)
             self.ctx.raytrace_ex(l)

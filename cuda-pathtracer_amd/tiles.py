@@ -73,12 +73,19 @@ class BandGather:
         self.send = torch.zeros((self.max_rows, width, 4), dtype=torch.uint8, device=device)
         self.recv = torch.zeros((world_size * self.max_rows, width, 4), dtype=torch.uint8, device=device)
 
+    def send_rows(self):
+        """This rank's part of the send buffer, uint8[rows_of_this_rank, W, 4]: a renderer that writes its surface here
+        (FrameRenderer(surface=...)) needs no staging copy before the collective."""
+        b, e = self.bands[self.rank]
+        return self.send[: e - b]
+
     def gather(self, band_surface, group=None):
-        """band_surface: uint8[rows_of_this_rank, W, 4].  Returns the padded gather buffer
+        """band_surface: uint8[rows_of_this_rank, W, 4] (send_rows() itself: no copy).  Returns the padded gather buffer
         (asynchronous with respect to the host on GPU streams)."""
         import torch.distributed as dist
         b, e = self.bands[self.rank]
-        self.send[: e - b].copy_(band_surface)
+        if band_surface.data_ptr() != self.send.data_ptr():
+            self.send[: e - b].copy_(band_surface)
         dist.all_gather_into_tensor(self.recv, self.send, group=group)
         return self.recv
 

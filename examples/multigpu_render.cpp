@@ -124,9 +124,9 @@ void rank_main(int rank, int world, Shared* sh)
   l.band_local_buffers = 1;
   if (ilv) { l.row_begin = 0; l.row_end = o.height; l.interleave_ranks = (uint32_t)world; l.interleave_rank = (uint32_t)rank; l.interleave_rows = o.interleave; }
   l.frame_count = o.spp;          // the spp static frames of one picture as ONE launch (== spp consecutive raytrace() calls)
+  l.reset_accumulation = 1;       // every frame starts a new accumulation: no clear of the accumulator in front of the launch
 
   auto frame = [&]() -> bool {
-    if (ptamd_device_memset(ctx, tfb, 0, (size_t)(y1 - y0) * o.width * 12, stream) != PTAMD_OK) return false;
     if (ptamd_raytrace_ex(ctx, &l) != PTAMD_OK) return false;
     return ncclAllGather(surface, gathered, band_bytes, ncclUint8, sh->comms[rank], stream) == ncclSuccess;
   };

@@ -246,6 +246,11 @@ typedef struct {
    * kernel PTAMD_KERNEL_AUTO / _BVH_RESTART).  Expensive and cheap parts of the picture are thereby spread over all
    * ranks; pixels are the same as in any other split (seeds come from frame coordinates). */
   uint32_t interleave_ranks, interleave_rank, interleave_rows;
+  /* != 0: the temporal framebuffer counts as zero on entry — the launch starts a new accumulation, exactly as if the
+   * caller had cleared the rows it renders first (the reference clears once, gpu_processor.cpp:255, and restarts an
+   * accumulation only through `moved`); saves the clear and the read.  With frame_count = N it applies to the first
+   * frame of the batch. */
+  uint32_t reset_accumulation;
 } ptamd_launch;
 
 int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch);

@@ -12,7 +12,7 @@ import argparse, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ap = argparse.ArgumentParser()
 ap.add_argument("--ranks", type=int, nargs="+", default=[8, 4, 2])
-ap.add_argument("--in-flight", type=int, nargs="+", default=[1, 2, 3])
+ap.add_argument("--in-flight", type=int, nargs="+", default=[1, 3, 4])
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--interleave", type=int, default=0, help="interleaved bands of this many rows instead of contiguous bands")
 ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_band_proxy.json"))

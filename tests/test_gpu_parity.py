@@ -267,6 +267,34 @@ def test_batched_frames_equal_consecutive_launches(P, O, gpu_ctx, indoor):
         gpu_ctx.raytrace_ex(l)
 
 
+def test_reset_accumulation_equals_a_cleared_accumulator(P, gpu_ctx, indoor):
+    """ptamd_launch.reset_accumulation: the launch that starts an accumulation treats the temporal framebuffer as zero —
+    bit for bit what clearing it first gives, whatever it held (NaNs included), for every kernel, sequential and batched,
+    full frame, band and interleaved rows."""
+    import torch
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    W, H, spp, B = 200, 121, 3, 4
+    for kernel in KERNELS:
+        for batched in ((False, True) if (kernel in ("persistent", "restart", "split")) else (False,)):
+            for kw in (dict(), dict(rows=(13, 77), band_local=True)) + ((dict(interleave=(3, 1, 8)),) if kernel == "restart" else ()):
+                clean = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H, **kw)
+                clean.render(spp=spp, bounces=B, kernel=kid(P, kernel), batched=batched)
+                dirty = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H, **kw)
+                dirty.accum.fill_(float("nan"))
+                dirty.accum[::2] = 123.5
+                dirty.render(spp=spp, bounces=B, kernel=kid(P, kernel), batched=batched, reset=True)
+                torch.cuda.synchronize()
+                rows = clean.rows if "interleave" not in kw else (0, H)
+                if kw.get("band_local") or "interleave" in kw:
+                    a, b = dirty.accum.cpu().numpy(), clean.accum.cpu().numpy()
+                    sa, sb = dirty.surface.cpu().numpy(), clean.surface.cpu().numpy()
+                else:                                   # full-frame buffers, band launch: compare the rendered rows only
+                    a, b = dirty.accum.cpu().numpy()[H - rows[1]:H - rows[0]], clean.accum.cpu().numpy()[H - rows[1]:H - rows[0]]
+                    sa, sb = dirty.surface.cpu().numpy()[rows[0]:rows[1]], clean.surface.cpu().numpy()[rows[0]:rows[1]]
+                assert_same(a, sa, b, sb, f"reset {kernel} batched={batched} {kw}")
+
+
 def test_batched_launches_in_flight_on_one_context(P, gpu_ctx, indoor):
     """two batched launches of ONE context on different streams run concurrently (machine_share = 2); each
     stream has its own sample scratch, so neither frame sees the other's samples — including when a scratch regrows."""
