@@ -62,6 +62,9 @@ namespace ptamd {
 #ifndef PT_RS_WAVES_PER_EU
 #define PT_RS_WAVES_PER_EU 6
 #endif
+#ifndef PT_CAM_FROM_KERNARG
+#define PT_CAM_FROM_KERNARG 1
+#endif
 #ifndef PT_LEAF_MIN
 #define PT_LEAF_MIN 64u /* lanes parked at a leaf that end a box phase early (64 = only when all are parked) */
 #endif
@@ -375,6 +378,30 @@ struct Nearest { float t, u, v; uint32_t idx; };
 typedef const __attribute__((address_space(4))) float* ConstF;
 PT_DEV ConstF as_constant(const float4* q) { return (ConstF)(uintptr_t)q; }
 
+// Launch constants that only the rare parts of a persistent kernel need (a tile's prologue, a finished path, a miss) are
+// re-read from the kernel-argument segment where they are used — KParams is every kernel's first argument — behind a
+// compiler barrier, instead of living in SGPRs for the whole launch: the round loop is short of scalar registers
+// (43 SGPR spills = v_writelane / v_readlane in the loop before this, 8.10 -> 8.33 Gsamples/s for the camera alone).
+#if PT_CAM_FROM_KERNARG
+template <typename T>
+PT_DEV T karg_load(uint32_t byte_offset)
+{
+  const __attribute__((address_space(4))) char* q = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset;
+  asm volatile("" : "+s"(q));
+  return *(const __attribute__((address_space(4))) T*)q;
+}
+#ifndef PT_KARG_ALL
+#define PT_KARG_ALL 1
+#endif
+#if PT_KARG_ALL
+#define PT_KARG(p, field) karg_load<decltype(KParams::field)>((uint32_t)__builtin_offsetof(KParams, field))
+#else
+#define PT_KARG(p, field) ((p).field)
+#endif
+#else
+#define PT_KARG(p, field) ((p).field)
+#endif
+
 PT_DEV Nearest nearest_lights(const KParams& p, f3 o, f3 d, Nearest n)
 {
   const ConstF lights = as_constant(p.lights);     // 8 floats per light: color.xyz, vec.xyz, emission, radius
@@ -451,7 +478,7 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
   } else {
     TexDesc tex;
     tex.w = (int32_t)f_as_u(s5.x); tex.h = (int32_t)f_as_u(s5.y); tex.nb_chan = (int32_t)f_as_u(s5.z); tex.pad = 0; tex.offset = f_as_u(s5.w);
-    const float* texel = p.texels + tex.offset + texture_idx(tex, uvx, uvy);
+    const float* texel = PT_KARG(p, texels) + tex.offset + texture_idx(tex, uvx, uvy);
     hit.diffuse_col = mk3(texel[0], texel[1], texel[2]);
     hit.specular_col = texel[3];
   }
@@ -460,7 +487,7 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
     const float4 s6 = sh[6];
     TexDesc nt;
     nt.w = (int32_t)f_as_u(s6.x); nt.h = (int32_t)f_as_u(s6.y); nt.nb_chan = (int32_t)f_as_u(s6.z); nt.pad = 0; nt.offset = f_as_u(s6.w);
-    const float* nx = p.texels + nt.offset + texture_idx(nt, uvx, uvy);
+    const float* nx = PT_KARG(p, texels) + nt.offset + texture_idx(nt, uvx, uvy);
     const f3 nn = normalize((mk3(nx[0], nx[1], nx[2]) * 2.0f) - 1.0f);
     const f3 binormal = normalize(cross(tangent, surface_normal));
     const f3 tx = tangent, ty = -binormal, tz = surface_normal;
@@ -476,7 +503,8 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
 PT_DEV f3 env_lookup(const KParams& p, f3 dir)
 {
   const float x = dir.x, y = dir.y, z = -dir.z; // raytrace.cu:60,197
-  const uint32_t n = p.cubemap_size;
+  const uint32_t n = PT_KARG(p, cubemap_size);
+  const float4* cubemap = PT_KARG(p, cubemap);
   const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
   int face;
   float m, s, t;
@@ -490,7 +518,7 @@ PT_DEV f3 env_lookup(const KParams& p, f3 dir)
     m = az;
     if (z >= 0.0f) { face = 4; s = x; t = -y; } else { face = 5; s = -x; t = -y; }
   }
-  const float4* base = p.cubemap + (size_t)face * n * n;
+  const float4* base = cubemap + (size_t)face * n * n;
   if (n == 1) { const float4 c = base[0]; return mk3(c.x, c.y, c.z); }
   const float u = (s / m + 1.0f) * 0.5f;
   const float v = (t / m + 1.0f) * 0.5f;
@@ -535,25 +563,39 @@ struct Path {
 PT_DEV void path_begin(const KParams& p, uint32_t x, uint32_t y, Path& st, uint32_t k = 0)
 {
   // raytrace.cu:227-229 with the reference's launch geometry (16x16 blocks, padded grid)
-  const uint32_t grid_x = p.width / 16u + 1u;
+  const uint32_t width = PT_KARG(p, width);
+  const uint32_t grid_x = width / 16u + 1u;
   const uint32_t tid = ((x >> 4) + (y >> 4) * grid_x) * 256u + (y & 15u) * 16u + (x & 15u);
   // k > 0 only in batched launches: frame frame_nb0 + k has hash_seed WangHash(frame_nb0 + k) (raytrace.cu:321)
-  const uint32_t hash_seed = k == 0 ? p.hash_seed : wang_hash(p.frame_nb0 + k);
+  const uint32_t hash_seed = k == 0 ? PT_KARG(p, hash_seed) : wang_hash(PT_KARG(p, frame_nb0) + k);
   xorwow_init(st.rng, hash_seed + tid);
 
+  // The 14 camera constants are only needed here, once per tile in the persistent kernels: they are re-read from the
+  // kernel-argument segment (KParams is every kernel's first argument) behind a compiler barrier instead of being kept
+  // in SGPRs for the whole launch, where they cost the round loop a dozen scalar spills (v_writelane / v_readlane).
+#if PT_CAM_FROM_KERNARG
+  ConstF cam = (ConstF)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(KParams, cam_pos));
+  asm volatile("" : "+s"(cam));
+  const f3 cam_pos = mk3(cam[0], cam[1], cam[2]), cam_p0 = mk3(cam[3], cam[4], cam[5]);
+  const f3 cam_u = mk3(cam[6], cam[7], cam[8]), cam_v = mk3(cam[9], cam[10], cam[11]);
+  const float focus_dist = cam[12], aperture = cam[13];
+#else
+  const f3 cam_pos = p.cam_pos, cam_p0 = p.cam_p0, cam_u = p.cam_u, cam_v = p.cam_v;
+  const float focus_dist = p.focus_dist, aperture = p.aperture;
+#endif
   // generateRay (intersection.cuh:75-97), pixel-invariant terms precomputed on the host
-  const int half_w = (int)(p.width / 2u), half_h = (int)(p.height / 2u);
-  const f3 screen_pos = (p.cam_p0 + (p.cam_u * (float)((int)x - half_w))) + (p.cam_v * (float)((int)y - half_h));
-  f3 dir = normalize(screen_pos - p.cam_pos);
-  f3 origin = p.cam_pos;
+  const int half_w = (int)(width / 2u), half_h = (int)(PT_KARG(p, height) / 2u);
+  const f3 screen_pos = (cam_p0 + (cam_u * (float)((int)x - half_w))) + (cam_v * (float)((int)y - half_h));
+  f3 dir = normalize(screen_pos - cam_pos);
+  f3 origin = cam_pos;
 
   // camera_dof (post_process.cuh:49-67)
-  const f3 focal_point = p.focus_dist * dir;
+  const f3 focal_point = focus_dist * dir;
   const float random_angle = (float)((double)(xorwow_uniform(st.rng) * 2.0f) * 3.14159265358979323846);
-  const float random_radius = xorwow_uniform(st.rng) * p.aperture;
+  const float random_radius = xorwow_uniform(st.rng) * aperture;
   float sn, cs;
   pt_sincosf(random_angle, sn, cs);
-  const f3 ap = (cs * p.cam_u + sn * p.cam_v) * random_radius;
+  const f3 ap = (cs * cam_u + sn * cam_v) * random_radius;
   st.d = normalize(focal_point - ap);
   st.o = origin + ap;
 
@@ -743,8 +785,8 @@ PT_DEV void path_finish(const KParams& p, const Path& st)
 // samples of a pixel to the accumulator in frame order, which is what consecutive launches do.
 PT_DEV void path_finish_sample(const KParams& p, const Path& st)
 {
-  const uint32_t rows = p.row_end - p.row_begin;
-  float* sp = p.samples_out + (((size_t)st.k() * rows + (st.y() - p.row_begin)) * p.width + st.x()) * 3;
+  const uint32_t row_begin = PT_KARG(p, row_begin), rows = PT_KARG(p, row_end) - row_begin;
+  float* sp = PT_KARG(p, samples_out) + (((size_t)st.k() * rows + (st.y() - row_begin)) * PT_KARG(p, width) + st.x()) * 3;
   sp[0] = clamp01(st.acc.x); sp[1] = clamp01(st.acc.y); sp[2] = clamp01(st.acc.z);
 }
 
@@ -1266,39 +1308,45 @@ pt_megakernel_restart(const KParams p)
       if (pool_rd >= 64u) {
         if (exhausted) break;
         if (tile >= tile_end) {
-          const uint32_t total = p.n_tiles * p.sample_count; // (tile, frame) pairs
+          const uint32_t tiles_per_ticket = PT_KARG(p, tiles_per_ticket);
+          const uint32_t total = PT_KARG(p, n_tiles) * PT_KARG(p, sample_count); // (tile, frame) pairs
           if (!have_ticket) {
+            uint32_t* heads = PT_KARG(p, tile_heads);
+            const uint32_t n_static = PT_KARG(p, n_static);
             for (;;) {
               uint32_t t = 0;
-              if (lane == 0) t = atomicAdd(p.tile_heads + head * PT_HEAD_STRIDE, 1u);
+              if (lane == 0) t = atomicAdd(heads + head * PT_HEAD_STRIDE, 1u);
               t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-              ticket = p.n_static + t * 8u + head;
-              if ((unsigned long long)ticket * p.tiles_per_ticket < total) break;
+              ticket = n_static + t * 8u + head;
+              if ((unsigned long long)ticket * tiles_per_ticket < total) break;
               head = (head + 1u) & 7u;
               if (++dry == 8u) break;
             }
             if (dry == 8u) { exhausted = true; break; }
           }
           have_ticket = false;
-          tile = ticket * p.tiles_per_ticket;
+          tile = ticket * tiles_per_ticket;
           if (tile >= total) { exhausted = true; break; }
-          tile_end = tile + p.tiles_per_ticket;
+          tile_end = tile + tiles_per_ticket;
           if (tile_end > total) tile_end = total;
         }
-        tile_k = tile / p.n_tiles;
-        const uint32_t tl = tile - tile_k * p.n_tiles;
-        tile_x0 = (tl % p.tiles_x) * PT_TILE_W;
         {
-          const uint32_t local_y0 = (tl / p.tiles_x) * PT_TILE_H;   // row inside this launch's share of the frame
-          if (p.ilv_ranks > 1u) {
+          const uint32_t n_tiles = PT_KARG(p, n_tiles), tiles_x = PT_KARG(p, tiles_x), row_begin = PT_KARG(p, row_begin);
+          tile_k = tile / n_tiles;
+          const uint32_t tl = tile - tile_k * n_tiles;
+          tile_x0 = (tl % tiles_x) * PT_TILE_W;
+          const uint32_t local_y0 = (tl / tiles_x) * PT_TILE_H;   // row inside this launch's share of the frame
+          const uint32_t ilv_ranks = PT_KARG(p, ilv_ranks);
+          if (ilv_ranks > 1u) {
             // interleaved bands: band j of ilv_rows rows belongs to rank j % ilv_ranks; this launch renders
             // the bands of rank ilv_rank and stores them one after the other
-            const uint32_t b = local_y0 / p.ilv_rows, within = local_y0 - b * p.ilv_rows;
-            tile_y0 = (b * p.ilv_ranks + p.ilv_rank) * p.ilv_rows + within;
+            const uint32_t ilv_rows = PT_KARG(p, ilv_rows);
+            const uint32_t b = local_y0 / ilv_rows, within = local_y0 - b * ilv_rows;
+            tile_y0 = (b * ilv_ranks + PT_KARG(p, ilv_rank)) * ilv_rows + within;
           } else {
-            tile_y0 = p.row_begin + local_y0;
+            tile_y0 = row_begin + local_y0;
           }
-          tile_row_delta = tile_y0 - (p.row_begin + local_y0);
+          tile_row_delta = tile_y0 - (row_begin + local_y0);
         }
         ++tile;
         {
