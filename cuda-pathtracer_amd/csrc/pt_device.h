@@ -243,6 +243,7 @@ struct KParams {
   uint32_t pool_lds_offset;   // != 0: the pools live in LDS this many bytes behind the start of the dynamic LDS (2 304 bytes per wave)
   uint32_t round_min, round_div;
   uint32_t walk_min;   // a box phase ends once fewer lanes than this are still walking (1: when none is)
+  uint32_t small_det;  // != 0: the scene's coordinates are <= 1e8, so Moller-Trumbore determinants stay below 2^125
   // four-wide walk (scenes that do not fit in LDS): 8 float4 per node, per-lane stacks in LDS with a global continuation
   const float4* nodes4;
   uint32_t n_nodes4;

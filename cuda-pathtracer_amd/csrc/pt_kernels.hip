@@ -85,8 +85,24 @@ struct Best { float t, u, v; uint32_t idx; };
 
 // intersection.cuh:102-135 on a {e1,e2,v0} record; identical operation order.
 // Accept rule: reference `t < best && t > 0` in storage order == lexicographic (t, idx).
+// 1.0f / x for x in [1e-7, 2^125], bit for bit the correctly rounded quotient (scripts/ubench/rcp_exact.hip checks all
+// 1 244 217 452 values on the device): the compiler's division sequence without v_div_scale / v_div_fixup, which are the
+// identity for a numerator of 1 and such a denominator — 7 VALU instead of 11.
+PT_DEV float rcp_exact_in_range(float x)
+{
+  const float y0 = __builtin_amdgcn_rcpf(x);
+  const float e0 = __builtin_fmaf(-x, y0, 1.0f);
+  const float y1 = __builtin_fmaf(e0, y0, y0);
+  const float r1 = __builtin_fmaf(-x, y1, 1.0f);
+  const float q1 = __builtin_fmaf(r1, y1, y1);
+  const float r2 = __builtin_fmaf(-x, q1, 1.0f);
+  return __builtin_fmaf(r2, y1, q1);
+}
+
+// small_det (wave-uniform, from the launcher): every determinant of this scene stays below 2^125 (coordinates <= 1e8),
+// so the survivors of the det >= 1e-7 test are inside rcp_exact_in_range's domain.
 template <bool ORDERED>
-PT_DEV void mt_test(float4 a, float4 b, float4 c, f3 o, f3 d, Best& best)
+PT_DEV void mt_test(float4 a, float4 b, float4 c, f3 o, f3 d, Best& best, bool small_det = false)
 {
   const f3 e1 = mk3(a.x, a.y, a.z);
   const f3 e2 = mk3(a.w, b.x, b.y);
@@ -96,7 +112,7 @@ PT_DEV void mt_test(float4 a, float4 b, float4 c, f3 o, f3 d, Best& best)
   // intersection.cuh:110 compares in double: (double)det < 1e-7.  1e-7f is the float nearest to
   // (and above) the double 1e-7 and no float lies between them, so `det < 1e-7f` decides identically.
   if (det < 1e-7f) return;
-  const float inv_det = 1.0f / det;
+  const float inv_det = small_det ? rcp_exact_in_range(det) : 1.0f / det;
   const f3 t_vec = o - v0;
   const float u = dot(t_vec, p_vec) * inv_det;
   if (u < 0 || u > 1) return;
@@ -304,7 +320,7 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
 
 template <bool STATS>
 PT_DEV void walk_leaf(const float4* tris, Walk& w, uint32_t leaf_first, uint32_t leaf_count, uint32_t& n_tris,
-                      uint32_t& wave_tri_iters)
+                      uint32_t& wave_tri_iters, bool small_det = false)
 {
   for (uint32_t k = 0; k < leaf_count; ++k) {
     if (STATS) {
@@ -312,7 +328,7 @@ PT_DEV void walk_leaf(const float4* tris, Walk& w, uint32_t leaf_first, uint32_t
       if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) ++wave_tri_iters;
     }
     const uint32_t ti = (leaf_first + k) * 3;
-    mt_test<false>(tris[ti], tris[ti + 1], tris[ti + 2], w.o, w.d, w.best);
+    mt_test<false>(tris[ti], tris[ti + 1], tris[ti + 2], w.o, w.d, w.best, small_det);
   }
   if (STATS) n_tris += leaf_count;
 }
@@ -1056,7 +1072,7 @@ PT_DEV void pool_load(const float4* slab, uint32_t e, Path& st)
 // once fewer than min(round_min, entering lanes / round_div) are unfinished.  node == PT_END on return: finished.
 template <bool STATS, bool NODES_IN_LDS>
 PT_DEV void traverse_round(const float4* nodes, const float4* tris, uint32_t n_nodes, f3 o, f3 d, Best& best, uint32_t& node,
-                           uint32_t round_min, uint32_t round_div, uint32_t walk_min, Counters& cnt)
+                           uint32_t round_min, uint32_t round_div, uint32_t walk_min, bool small_det, Counters& cnt)
 {
   Walk w;
   walk_init(w, o, d, n_nodes);
@@ -1072,7 +1088,7 @@ PT_DEV void traverse_round(const float4* nodes, const float4* tris, uint32_t n_n
     uint32_t leaf_first, leaf_count;
     if (NODES_IN_LDS && !STATS && PT_ASM_WALK) walk_to_leaf_lds(lds_nodes, w, leaf_first, leaf_count, walk_min);
     else walk_to_leaf<STATS>(nodes, w, leaf_first, leaf_count, cnt.nodes, cnt.wave_node_iters, walk_min);
-    if (leaf_count != 0u) walk_leaf<STATS>(tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters);
+    if (leaf_count != 0u) walk_leaf<STATS>(tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters, small_det);
     if ((uint32_t)__popcll(__ballot(w.node != PT_END)) < t_eff) break;
   }
   best = w.best;
@@ -1201,7 +1217,7 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
 // One round of the wide walk for the lanes that call it (see traverse_round): cur == PT_NONE on return: finished.
 template <bool STATS>
 PT_DEV void traverse_round4(const float4* nodes4, const float4* tris, const Stack4& stk, f3 o, f3 d, Best& best, uint32_t& cur,
-                            uint32_t& sp, uint32_t round_min, uint32_t round_div, uint32_t walk_min, Counters& cnt)
+                            uint32_t& sp, uint32_t round_min, uint32_t round_div, uint32_t walk_min, bool small_det, Counters& cnt)
 {
   Walk w;
   walk_init(w, o, d, 1u);
@@ -1241,10 +1257,10 @@ PT_DEV void traverse_round4(const float4* nodes4, const float4* tris, const Stac
             const unsigned long long act = __ballot(1);
             if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) ++cnt.wave_tri_iters;
           }
-          mt_test<false>(r[3 * k], r[3 * k + 1], r[3 * k + 2], w.o, w.d, w.best);
+          mt_test<false>(r[3 * k], r[3 * k + 1], r[3 * k + 2], w.o, w.d, w.best, small_det);
         }
       if (STATS) cnt.tris += count < 3u ? count : 3u;
-      if (count > 3u) walk_leaf<STATS>(tris, w, first + 3u, count - 3u, cnt.tris, cnt.wave_tri_iters);
+      if (count > 3u) walk_leaf<STATS>(tris, w, first + 3u, count - 3u, cnt.tris, cnt.wave_tri_iters, small_det);
       cur = stack4_pop(stk, sp, w.best.t);
     }
     if ((uint32_t)__popcll(__ballot(cur != PT_NONE)) < t_eff) break;
@@ -1398,10 +1414,10 @@ pt_megakernel_restart(const KParams p)
         if (STATS) cnt.rays++;
       }
       if (WIDE) {
-        traverse_round4<STATS>(p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, cnt);
+        traverse_round4<STATS>(p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, p.small_det != 0u, cnt);
         node = cur == PT_NONE ? PT_END : 0u;
       } else {
-        traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.walk_min, cnt);
+        traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.walk_min, p.small_det != 0u, cnt);
       }
       if (STATS) {   // fetch_events: rounds of this wave; fetch_rays: walks that completed in them
         if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) cnt.fetch_events++;
@@ -1847,7 +1863,7 @@ __global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(const KParams p,
   Best best;
   best.t = PT_MAX_DIST; best.u = best.v = 0.f; best.idx = PT_END;
   uint32_t cur = (live && p.n_nodes4) ? 0u : PT_NONE, sp = 0u;
-  if (live) traverse_round4<false>(p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, cnt);
+  if (live) traverse_round4<false>(p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, p.small_det != 0u, cnt);
   if (!live) return;
   Nearest nr;
   nr.t = best.t; nr.u = best.u; nr.v = best.v; nr.idx = best.idx;

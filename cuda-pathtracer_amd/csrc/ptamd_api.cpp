@@ -38,7 +38,8 @@ struct DeviceScene {
   uint32_t n_faces = 0, n_lights = 0, n_nodes = 0, n_materials = 0, n_textures = 0;
   uint32_t n_bvh_tris = 0; // triangle records behind the BVH leaves (>= n_faces with split references)
   uint32_t n_nodes4 = 0, depth4 = 0;
-  float extent = 0.0f;       // largest |coordinate| of the scene (bvh_builder.cpp)
+  float extent = 0.0f;       // largest finite |coordinate| of the scene (bvh_builder.cpp)
+  bool all_finite = true;    // no NaN or infinite vertex coordinate
   float margin_floor = 0.0f; // smallest inflation of any box face: what the slab test's rounding error must stay below
   ptamd_scene_info info{};
 };
@@ -81,6 +82,7 @@ struct ptamd_context {
   bool pool_in_lds = true;                // restart kernel: pools of fresh paths in LDS when they fit (PTAMD_POOL_LDS=0: always the global slab)
   uint32_t treelet_nodes = 512;           // wide walk: nodes of the top of the tree staged in LDS (PTAMD_TREELET; with LDS pools 341 / 512 / 640: 1286 / 1291 / 1275)
   uint32_t walk_min4 = 16;                // the same threshold for the four-wide walk (PTAMD_WALK_MIN4; 1/4/8/16/24: 813/902/960/994/971 Msamples/s)
+  bool short_rcp = true;                  // restart kernel: 7-instruction exact 1/det where the scene allows it (PTAMD_SHORT_RCP=0: always the full division)
   uint32_t tiles_per_ticket = 1;
 };
 
@@ -189,6 +191,9 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   p.cubemap = cm.faces; p.cubemap_size = cm.size;
   p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
   p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4;
+  // finite edges of at most 2e8 per axis and unit directions: det = e1 . (dir x e2) is far below 2^125 (or NaN, which
+  // both forms of the reciprocal pass on)
+  p.small_det = ctx->short_rcp && s.all_finite && s.extent <= 1.0e8f ? 1u : 0u;
 
   // generateRay's pixel-invariant part (intersection.cuh:79-89)
   const ptamd_camera& cam = l->camera;
@@ -498,6 +503,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
     int v = std::atoi(e);
     ctx->walk_min4 = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
+  if (const char* e = std::getenv("PTAMD_SHORT_RCP")) ctx->short_rcp = std::atoi(e) != 0; // tuning knob
   if (const char* e = std::getenv("PTAMD_POOL_LDS")) ctx->pool_in_lds = std::atoi(e) != 0; // tuning knob
   if (const char* e = std::getenv("PTAMD_TREELET")) { // tuning knob
     int v = std::atoi(e);
@@ -619,7 +625,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   PT_HIP(hipSetDevice(ctx->device));
   DeviceScene d;
   d.n_faces = sc->n_faces; d.n_lights = sc->n_lights; d.n_nodes = bvh.n_nodes; d.n_bvh_tris = bvh.n_tris;
-  d.extent = bvh.extent; d.margin_floor = bvh.margin_floor;
+  d.extent = bvh.extent; d.all_finite = bvh.all_finite; d.margin_floor = bvh.margin_floor;
   d.n_nodes4 = bvh.n_nodes4; d.depth4 = bvh.depth4;
   d.n_materials = sc->n_materials; d.n_textures = sc->n_textures;
   if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
@@ -752,6 +758,7 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   p.nodes = s.nodes; p.tris_bvh = s.tris_bvh; p.tris_brute = s.tris_brute; p.lights = s.lights;
   p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
   p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4;
+  p.small_det = 0u;                           // caller-supplied directions need not be unit vectors
   p.stack_lds_entries = 3u * s.depth4 + 1u;   // PTAMD_KERNEL_BVH_RESTART: the four-wide walk, whole stack in LDS
   float* d_rays = nullptr;
   int4* d_out = nullptr;

@@ -284,6 +284,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   b.max_leaf = max_leaf;
   b.prims.resize(n_faces);
   float extent = 0.0f;   // largest finite |coordinate| of the scene
+  bool all_finite = true;
   for (uint32_t i = 0; i < n_faces; ++i) {
     Prim& p = b.prims[i];
     p.face = i;
@@ -295,6 +296,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
         // face can never pass Moller-Trumbore either way)
         if (v[a] == v[a]) { p.box.lo[a] = std::min(p.box.lo[a], v[a]); p.box.hi[a] = std::max(p.box.hi[a], v[a]); }
         if (std::fabs(v[a]) <= std::numeric_limits<float>::max()) extent = std::max(extent, std::fabs(v[a]));
+        else all_finite = false;
       }
     }
     for (int a = 0; a < 3; ++a) {
@@ -355,6 +357,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   // (ptamd_api.cpp: far-origin check against Bvh::margin_floor).
   const float origin_margin = extent * (1.0f / 1048576.0f);
   out.extent = extent;
+  out.all_finite = all_finite;
   out.margin_floor = margin + origin_margin;
   uint32_t tri_cursor = 0;
   std::vector<uint32_t> leaf_info(b.nodes.size(), 0u);   // build-node id -> first_tri | count << 24 (leaves only)

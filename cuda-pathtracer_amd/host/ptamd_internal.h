@@ -73,7 +73,8 @@ struct Bvh {
   // Nodes are numbered breadth-first (node 0 = root).  Leaves point into `tris`.
   std::vector<float> nodes4;
   uint32_t n_nodes4 = 0, depth4 = 0;
-  float extent = 0.0f;           // largest |coordinate| of the scene
+  float extent = 0.0f;           // largest finite |coordinate| of the scene
+  bool all_finite = true;        // no vertex coordinate is NaN or infinite
   float margin_floor = 0.0f;     // smallest inflation any box face received (absolute margin + extent * 2^-20)
 };
 
