@@ -1,0 +1,11 @@
+#!/bin/bash
+# restart kernel: 2 workgroups x 12 waves (default) against 1 workgroup x 16 waves per CU (one scene copy, 108 KB of LDS left)
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
+for v in "default=" "wg1024x4=-DPT_RS_THREADS=1024 -DPT_RS_WAVES_PER_EU=4" "wg512x4=-DPT_RS_THREADS=512 -DPT_RS_WAVES_PER_EU=4" "default2="; do
+  name=${v%%=*}; flags=${v#*=}
+  make -s -B lib EXTRA_HIPFLAGS="$flags" 2>>$OUT/wg.err || { echo "$name: build failed"; continue; }
+  for rep in 1 2; do
+    timeout -k 10 180 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra 2>>$OUT/wg.err | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$name', d['value'], d['roofline']['kernel_ms_per_launch'])" || { echo "$name: bench failed"; break; }
+  done
+done
+make -s -B lib 2>>$OUT/wg.err

@@ -7,13 +7,18 @@ import torch  # noqa: E402
 import cuda_pathtracer_amd as P  # noqa: E402
 
 W, H, B = 1920, int(os.environ.get("HEIGHT", 1080)), int(os.environ.get("BOUNCES", 4))
+SPP = int(os.environ.get("SPP", 1))            # frames per launch (the batched launch of the bench is 4)
+ONLY = os.environ.get("ONLY")                  # e.g. ONLY=restart
 hs = P.HostScene.load(os.path.join(ROOT, "assets", "indoor.scene"))
 with P.Context(0) as ctx:
     sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(P.cubemap_for_scene(hs))
     fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H)
     for name, k in (("tile", P.KERNEL_BVH), ("persistent", P.KERNEL_BVH_PERSISTENT), ("restart", P.KERNEL_BVH_RESTART)):
+        if (ONLY and name != ONLY) or (SPP > 1 and name == "tile"):
+            continue
         fr.reset()
-        l = ctx.make_launch(fr.surface, fr.accum, sid, cid, hs.camera_struct(), W, H, frame_nb=1, bounces=B, kernel=k)
+        l = ctx.make_launch(fr.surface, fr.accum, sid, cid, hs.camera_struct(), W, H, frame_nb=1, bounces=B, kernel=k,
+                            frame_count=SPP)
         s = ctx.raytrace_stats(l)
         print(name, {k2: v for k2, v in s.items() if v})
         print("  box-loop lane utilisation %.3f, tri-loop lane utilisation %.3f, box iters/ray(wave) %.2f" % (
