@@ -1,7 +1,9 @@
 #!/bin/bash
-# restart kernel: 2 workgroups x 12 waves (default) against 1 workgroup x 16 waves per CU (one scene copy, 108 KB of LDS left)
+# restart kernel: workgroup shapes / register budgets, rebuilt per variant ("name=flags" arguments; no arguments: the set below)
+#   2 workgroups x 12 waves (default) against 1 workgroup x 16 waves per CU (one scene copy, 108 KB of LDS left) and 2 x 8
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
-for v in "default=" "wg1024x4=-DPT_RS_THREADS=1024 -DPT_RS_WAVES_PER_EU=4" "wg512x4=-DPT_RS_THREADS=512 -DPT_RS_WAVES_PER_EU=4" "default2="; do
+[ $# -gt 0 ] || set -- "default=" "wg1024x4=-DPT_RS_THREADS=1024 -DPT_RS_WAVES_PER_EU=4" "wg512x4=-DPT_RS_THREADS=512 -DPT_RS_WAVES_PER_EU=4" "default2="
+for v in "$@"; do
   name=${v%%=*}; flags=${v#*=}
   make -s -B lib EXTRA_HIPFLAGS="$flags" 2>>$OUT/wg.err || { echo "$name: build failed"; continue; }
   for rep in 1 2; do
