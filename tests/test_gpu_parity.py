@@ -620,6 +620,27 @@ def test_scene_with_huge_coordinates(P, O, gpu_ctx):
         assert_same(acc, rgba, *ref, f"far scene/{kernel}")
 
 
+def test_scenes_outside_the_short_reciprocal_range(P, O, gpu_ctx):
+    """The restart kernel divides by the Moller-Trumbore determinant with a 7-instruction exact reciprocal only where the
+    launcher can bound the determinant (all vertices finite and <= 1e8, ptamd_api.cpp: small_det).  One far vertex (3e9), an
+    infinite one and a NaN one switch it off: every variant still renders the oracle's pixels."""
+    rng = np.random.default_rng(77)
+    cube = synthetic_cubemap(rng, 2)
+    lights = [((0.0, 0.5, 1.0), (1.0, 0.9, 0.8), 4.0, 0.8)]
+    base = random_soup(rng, 60, extent=1.2, size=0.9)
+    for name, bad in (("far vertex", 3.0e9), ("infinite vertex", np.inf), ("nan vertex", np.nan)):
+        tris = base.copy()
+        tris[7, 1, 0] = np.float32(bad)          # one coordinate of one face
+        if name == "far vertex":
+            tris[9] = tris[9] * np.float32(1.0e9)   # and a whole face out there: huge determinants for every ray
+        hs = make_scene(P, tris, lights=lights)
+        ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 48, 32, spp=2, bounces=4)
+        assert (ref[0] > 0).any()
+        for kernel in KERNELS:
+            acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 4, kid(P, kernel))
+            assert_same(acc, rgba, *ref, f"{name}/{kernel}")
+
+
 def test_stats_are_consistent(P, O, gpu_ctx, indoor):
     """Instrumented launch: ray/mesh-hit counts equal the oracle's, BVH tests far fewer triangles."""
     import torch
