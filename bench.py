@@ -90,6 +90,9 @@ def parse_args(argv=None):
                          "bands with --interleave ROWS): the single-GPU proxy of scripts/band_proxy.py")
     ap.add_argument("--no-extra", action="store_true",
                     help="headline only: skip value_unpipelined / value_sequential / other_configs (profiling runs)")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="untimed rendering before the W warm-up steps of every leg, so that the timed steps run at the chip's "
+                         "steady clocks (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_latest.json"),
@@ -225,7 +228,7 @@ class Workload:
     def frames_per_launch(self):
         return self.spp if self.batched else 1
 
-    def step(self, ev=None):
+    def step(self, ev=None, gather=True):
         torch = self.torch
         fr, bg, st = self.slots[self.counter % self.n_slots]
         self.counter += 1
@@ -237,7 +240,7 @@ class Workload:
             fr.render(spp=self.spp, bounces=self.B, kernel=self.kernel, stream=st, batched=self.batched, reset=True)
             if ev is not None:
                 ev[1].record(st)
-            if bg is not None:
+            if bg is not None and gather:
                 bg.gather(fr.surface)  # one RCCL all-gather of the RGBA8 bands per frame
 
     def barrier(self):
@@ -245,12 +248,20 @@ class Workload:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def run(self, steps, warmup):
-        """W untimed steps, then exactly K timed steps between barriers.  Returns (wall seconds, mean ms between the
-        HIP events that bracket one step's launches on its stream)."""
+    def run(self, steps, warmup, settle_ms=0.0):
+        """`settle_ms` of untimed rendering (no collective: ranks need not agree on the count), W untimed steps, then
+        exactly K timed steps between barriers.  Returns (wall seconds, mean ms between the HIP events that bracket one
+        step's launches on its stream).  The settle phase exists because an idle MI355X needs ~30 ms of load to reach its
+        steady clocks (scripts/gpu_ramp.py: launches 5..25 after 3 s of idling run 6.5 % slower than launch 30 onwards),
+        longer than the W + K steps of a default run."""
         torch = self.torch
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         with _StdoutToStderr():  # first collective = communicator setup (and RCCL's banner)
+            t_end = time.perf_counter() + settle_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(self.n_slots):
+                    self.step(gather=False)
+                torch.cuda.synchronize()
             for _ in range(warmup):
                 self.step()
             self.barrier()
@@ -371,7 +382,7 @@ def main():
     wl = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, n_slots, args.share, not args.sequential,
                   local_rank, world, rank, gather, rows, interleave)
     proxy = rows is not None or (interleave is not None and world == 1)
-    dt, step_ms = wl.run(args.steps, args.warmup)
+    dt, step_ms = wl.run(args.steps, args.warmup, args.settle_ms)
     frames_per_launch = wl.frames_per_launch
     launches_per_step = spp // frames_per_launch
     # one step = launches_per_step megakernel launches (+ the small resolve kernel when batched) back to back on its stream
@@ -391,7 +402,7 @@ def main():
         # (a) the same batched launch, one at a time: a frame's latency and the unpipelined rate
         if n_slots > 1:
             solo = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, 1, False, not args.sequential, local_rank)
-            sdt, s_ms = solo.run(k2, 2)
+            sdt, s_ms = solo.run(k2, 2, args.settle_ms)
             solo.close()
             extra["value_unpipelined"] = round(W * H * spp * k2 / sdt / 1e6, 3)
             extra["ms_per_frame"] = round(s_ms, 4)
@@ -402,7 +413,7 @@ def main():
         if not args.sequential:
             # (PTAMD_KERNEL_AUTO: what a host that calls raytrace() once per spp gets — the persistent kernel on this scene)
             seq = Workload(P, torch, dist, hs, cube, W, H, spp, B, "auto" if args.kernel == "restart" else args.kernel, 1, False, False, local_rank)
-            qdt, q_ms = seq.run(k2, 2)
+            qdt, q_ms = seq.run(k2, 2, args.settle_ms)
             seq.close()
             extra["value_sequential"] = round(W * H * spp * k2 / qdt / 1e6, 3)
             extra["ms_per_frame_sequential"] = round(q_ms, 4)
@@ -418,7 +429,7 @@ def main():
                 if ap is not None:
                     sc.camera["aperture"] = ap
                 o = Workload(P, torch, dist, sc, P.cubemap_for_scene(sc), w2, h2, s2, b2, "restart", 2, True, True, local_rank)
-                odt, o_ms = o.run(k, 1)
+                odt, o_ms = o.run(k, 1, args.settle_ms)
                 oi = o.info
                 o.close()
                 others.append({"workload": name, "value": round(w2 * h2 * s2 * k / odt / 1e6, 3), "unit": "Msamples/s",
@@ -487,6 +498,9 @@ def main():
                                    + (f", interleaved {interleave[2]}-row bands of rank {interleave[1]}/{interleave[0]} only" if (proxy and interleave) else ""),
                        "kernel": args.kernel, "launches_per_frame": launches_per_step, "frames_per_launch": frames_per_launch,
                        "faces": info["n_faces"], "bvh_nodes": info["n_nodes"], "frames_in_flight": n_slots,
+                       # untimed rendering ahead of the W warm-up steps (the chip's clocks settle ~30 ms after an idle
+                       # period: scripts/gpu_ramp.py); the timed region is exactly `steps` steps
+                       "untimed_settle_ms": args.settle_ms,
                        "parallelism": (f"rows/{world}" if interleave is None or world == 1 else f"interleaved {interleave[2]}-row bands over {world} ranks")
                                       + (" + RCCL all-gather of RGBA8 bands" if world > 1 else "")},
             "roofline": roof,
