@@ -253,6 +253,10 @@ typedef struct {
   uint32_t reset_accumulation;
 } ptamd_launch;
 
+/* Asynchronous on launch->stream.  Once a configuration (frame size, frame_count, stream) has been launched once — the
+ * first launch sizes that stream's sample scratch, which synchronises and allocates — later launches only enqueue
+ * kernels and memsets, so a host may capture them into a hipGraph (hipStreamBeginCapture on launch->stream) and replay it:
+ * tests/test_gpu_parity.py test_batched_launch_is_graph_capturable.  The captured launch keeps its frame_nb / seeds. */
 int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch);
 /* Rows an interleaved launch renders (= rows its band-local buffers must hold): the bands j = rank, rank + ranks, ... of
  * band_rows rows each, the last band of the frame possibly shorter. */

@@ -323,6 +323,35 @@ def test_batched_launches_in_flight_on_one_context(P, gpu_ctx, indoor):
                 assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *want[first], f"in-flight batched {W}x{H} frame {first} rep {rep}")
 
 
+def test_batched_launch_is_graph_capturable(P, gpu_ctx, indoor):
+    """A warmed-up batched launch (megakernel + resolve pass, ticket heads re-zeroed by the resolve pass) makes no
+    synchronising or allocating HIP call, so a host may capture it into a hipGraph and replay it: every replay produces the
+    eager launch's accumulator and surface bit for bit."""
+    needs_batched_default()
+    import torch
+    W, H, spp = 640, 360, 4
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    eager = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H)
+    eager.render(spp=spp, bounces=4, batched=True, reset=True)
+    torch.cuda.synchronize()
+    want = (eager.accum.cpu().numpy(), eager.surface.cpu().numpy())
+    fr = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fr.render(spp=spp, bounces=4, batched=True, reset=True, stream=side)     # warm-up: this stream's sample scratch
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        fr.render(spp=spp, bounces=4, batched=True, reset=True, stream=torch.cuda.current_stream())
+    for rep in range(3):
+        fr.accum.fill_(7.0)
+        fr.surface.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *want, f"graph replay {rep}")
+
+
 def test_trace_rays_device_equals_oracle(P, O, gpu_ctx):
     """Nearest-hit records (kind, index, t bits) of both device traversals == brute-force oracle,
     including light spheres."""
