@@ -36,6 +36,55 @@ PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 // cutils_math.h:70-74,1557: v * (1.0f / sqrtf(dot))
 PT_DEV f3 normalize(f3 v) { float inv_len = 1.0f / __builtin_sqrtf(dot(v, v)); return v * inv_len; }
+
+#ifndef PT_SHORT_MATH
+#define PT_SHORT_MATH 1   /* 0: the compiler's full sqrt / division everywhere (A/B: scripts/gpu_r2_wg.sh "x=-DPT_SHORT_MATH=0") */
+#endif
+// ---- short forms of the two IEEE operations the shading code is full of.  Each is the compiler's own expansion minus
+// the steps that are the identity inside a range; scripts/ubench/sqrt_exact.hip and rcp_exact.hip compare them with the
+// full forms on ALL 2^32 binary32 patterns on the device (0 mismatches inside the ranges stated here).
+// 1.0f / x, correctly rounded, for 2^-95 <= |x| <= 2^125: no v_div_scale / v_div_fixup (7 VALU instead of 11).
+PT_DEV float rcp_exact_in_range(float x)
+{
+  const float y0 = __builtin_amdgcn_rcpf(x);
+  const float e0 = __builtin_fmaf(-x, y0, 1.0f);
+  const float y1 = __builtin_fmaf(e0, y0, y0);
+  const float r1 = __builtin_fmaf(-x, y1, 1.0f);
+  const float q1 = __builtin_fmaf(r1, y1, y1);
+  const float r2 = __builtin_fmaf(-x, q1, 1.0f);
+  return __builtin_fmaf(r2, y1, q1);
+}
+// sqrtf(x), correctly rounded, for x == 0, 2^-96 <= x <= +inf and NaN: v_sqrt_f32 and the "is a neighbour better" step,
+// without the 2^32 pre-scaling of small inputs and the 0 / inf fix-up (9 VALU instead of 15).
+PT_DEV float sqrt_exact_in_range(float x)
+{
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+  s = rd <= 0.0f ? sd : s;
+  s = ru > 0.0f ? su : s;
+  return s;
+}
+// true when no active lane of the wave violates c: the short forms are taken by whole waves only
+PT_DEV bool wave_all(bool c) { return __builtin_amdgcn_ballot_w64(!c) == 0ull; }
+// normalize() for the hot spots of path_post: same value, 16 VALU instead of 26 for the reciprocal length whenever
+// every lane's squared length is in [2^-96, inf)
+PT_DEV f3 normalize_hot(f3 v)
+{
+  const float d = dot(v, v);
+  float inv_len;
+  if (PT_SHORT_MATH && wave_all(d >= 0x1p-96f && d < __builtin_inff())) inv_len = rcp_exact_in_range(sqrt_exact_in_range(d));
+  else inv_len = 1.0f / __builtin_sqrtf(d);
+  return v * inv_len;
+}
+// 1.0f / x where x is usually, not always, inside rcp_exact_in_range's domain
+PT_DEV float rcp_hot(float x)
+{
+  if (PT_SHORT_MATH && wave_all(x >= 0x1p-95f && x <= 0x1p125f)) return rcp_exact_in_range(x);
+  return 1.0f / x;
+}
+// sqrtf(x) for an x known to be 0 or >= 2^-96 (a uniform variate, 1 - a uniform variate)
+PT_DEV float sqrt_hot(float x) { return PT_SHORT_MATH ? sqrt_exact_in_range(x) : __builtin_sqrtf(x); }
 // cutils_math.h:1678
 PT_DEV f3 reflect(f3 i, f3 n) { return i - (2.0f * n) * dot(n, i); }
 // cutils_math.h:1722

@@ -85,20 +85,6 @@ struct Best { float t, u, v; uint32_t idx; };
 
 // intersection.cuh:102-135 on a {e1,e2,v0} record; identical operation order.
 // Accept rule: reference `t < best && t > 0` in storage order == lexicographic (t, idx).
-// 1.0f / x for x in [1e-7, 2^125], bit for bit the correctly rounded quotient (scripts/ubench/rcp_exact.hip checks all
-// 1 244 217 452 values on the device): the compiler's division sequence without v_div_scale / v_div_fixup, which are the
-// identity for a numerator of 1 and such a denominator — 7 VALU instead of 11.
-PT_DEV float rcp_exact_in_range(float x)
-{
-  const float y0 = __builtin_amdgcn_rcpf(x);
-  const float e0 = __builtin_fmaf(-x, y0, 1.0f);
-  const float y1 = __builtin_fmaf(e0, y0, y0);
-  const float r1 = __builtin_fmaf(-x, y1, 1.0f);
-  const float q1 = __builtin_fmaf(r1, y1, y1);
-  const float r2 = __builtin_fmaf(-x, q1, 1.0f);
-  return __builtin_fmaf(r2, y1, q1);
-}
-
 // small_det (wave-uniform, from the launcher): every determinant of this scene stays below 2^125 (coordinates <= 1e8),
 // so the survivors of the det >= 1e-7 test are inside rcp_exact_in_range's domain.
 template <bool ORDERED>
@@ -656,7 +642,7 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
       st.acc = st.acc + env * st.throughput;
       const float pmax = __builtin_fmaxf(st.throughput.x, __builtin_fmaxf(st.throughput.y, st.throughput.z));
       if (r1 > pmax && st.b() > 1u) return true;
-      st.throughput = st.throughput * (1.0f / pmax);
+      st.throughput = st.throughput * rcp_hot(pmax);
       ++st.bk;
       if ((int)st.b() >= max_bounces) return true;
       r1 = xorwow_uniform(st.rng);
@@ -667,7 +653,7 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
   const f3 d = st.d;
   const float cos_theta = dot(inter.normal, d);
   f3 oriented_normal = inter.normal;
-  const f3 spec = normalize(reflect(d, inter.normal));
+  const f3 spec = normalize_hot(reflect(d, inter.normal));
   const f3 direct_light = inter.diffuse_col / 0.5f; // brdf_lambert / pdf_lambert (brdf.cuh:14-31)
   if (inter.ior == 1.0f || inter.light >= 0) {
     if (inter.light >= 0) {
@@ -675,14 +661,15 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
       st.acc = st.acc + (mk3(la.x, la.y, la.z) * lb.z) * st.throughput;
     }
     const float phi = (float)((double)2.0f * 3.14159265358979323846 * (double)xorwow_uniform(st.rng));
-    const float sin_t = __builtin_sqrtf(r1);
-    const float cos_t = __builtin_sqrtf(1.f - r1);
+    // r1 is a uniform variate in (0, 1] (or 0): both arguments are 0 or >= 2^-33
+    const float sin_t = sqrt_hot(r1);
+    const float cos_t = sqrt_hot(1.f - r1);
     const f3 axis = (__builtin_fabsf(oriented_normal.x) >= 0.1f) /* == (double)|x| > .1: 0.1f is the first float above the double .1 */ ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
-    const f3 u = normalize(cross(axis, oriented_normal));
+    const f3 u = normalize_hot(cross(axis, oriented_normal));
     const f3 v = cross(oriented_normal, u);
     float sphi, cphi;
     pt_sincosf(phi, sphi, cphi);
-    const f3 dd = normalize(v * sin_t * cphi + u * sphi * sin_t + oriented_normal * cos_t);
+    const f3 dd = normalize_hot(v * sin_t * cphi + u * sphi * sin_t + oriented_normal * cos_t);
     st.o = st.o + d * inter.dist;
     st.d = mix(dd, spec, inter.specular_col);
     st.o = st.o + st.d * 0.03f;
@@ -720,7 +707,7 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
   }
   const float pmax = __builtin_fmaxf(st.throughput.x, __builtin_fmaxf(st.throughput.y, st.throughput.z));
   if (r1 > pmax && st.b() > 1u) return true;
-  st.throughput = st.throughput * (1.0f / pmax);
+  st.throughput = st.throughput * rcp_hot(pmax);
   ++st.bk;
   return (int)st.b() >= max_bounces;
 }
