@@ -223,7 +223,10 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
 // reach a leaf they hit or run off the tree.  v64..v69, v72 and v74 are scratch (clobbered); masks live in
 // compiler-allocated SGPR pairs.  Hazards: a VALU that reads an SGPR mask written by a VALU
 // compare needs 2 wait states (s_nop 1), exactly as hipcc pads it; SALU consumers are interlocked.
-PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count, uint32_t walk_min = 1u)
+// `state` is the walk's position in the loop's own terms (below): the LDS address of the next box, or 0xFFFF when the walk is
+// over; it stays in that form between the box phases of a round (traverse_round) — converting it to a node index and
+// back costs four VALU per phase.
+PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w, uint32_t& leaf_first, uint32_t& leaf_count, uint32_t walk_min)
 {
   // COMPACT LDS nodes (stage_scene), two arrays of 32-byte records, N nodes each:
   //   boxes[n] at lds_nodes + 32 n:          dwords 0..3 lo.xyz hi.x | 4..5 hi.yz | 6 leaf word
@@ -234,8 +237,6 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
   // so one v_cndmask with sub-dword selects yields the next state and one unsigned compare says whether to keep
   // walking: 21 VALU, 4 SALU and 8 LDS cycles per iteration (the plain layout took 33 / 20 / 10).  A lane that parks
   // stops executing; its leaf word and miss link are fetched once, after the loop.
-  uint32_t state = w.node == PT_END ? 0xFFFFu : lds_nodes + (w.node << 5);
-  const uint32_t lnk = w.n_nodes * 32u + w.oct * 4u;        // from a node's box to its link word for this ray's octant
   unsigned long long save;
   uint32_t walkers;   // lanes still in the box loop; the loop runs while walkers >= walk_min (walk_min 1: until none is left)
   asm volatile(
@@ -289,19 +290,27 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
       : "v64", "v65", "v66", "v67", "v68", "v69", "v72", "v74", "vcc", "scc", "memory");
   leaf_first = 0u;
   leaf_count = 0u;
-  if (state == 0xFFFFu) {
-    w.node = PT_END;
-  } else if (state < 0x8000u) {                              // still walking when the phase ended (walk_min > 1)
-    w.node = (state - lds_nodes) >> 5;
-  } else {                                                   // parked: 0x8000 | (address of the leaf's node >> 1)
+  if (state >= 0x8000u && state != 0xFFFFu) {               // parked: 0x8000 | (address of the leaf's node >> 1)
     typedef const __attribute__((address_space(3))) uint32_t* LdsU32;
     const uint32_t leaf_addr = (state & 0x7FFFu) << 1;
     const uint32_t info = *(LdsU32)(uintptr_t)(leaf_addr + 24u);
-    const uint32_t miss = *(LdsU32)(uintptr_t)(leaf_addr + lnk) >> 16;
+    state = *(LdsU32)(uintptr_t)(leaf_addr + lnk) >> 16;    // the leaf's miss code: where the walk goes on after the tests
     leaf_first = info & 0xFFFFFFu;
     leaf_count = info >> 24;
-    w.node = miss == 0xFFFFu ? PT_END : (miss - lds_nodes) >> 5;
   }
+}
+
+// from a node's box to its link word for this ray's octant
+PT_DEV uint32_t walk_lds_link_offset(const Walk& w) { return w.n_nodes * 32u + w.oct * 4u; }
+PT_DEV uint32_t walk_lds_state(uint32_t lds_nodes, uint32_t node) { return node == PT_END ? 0xFFFFu : lds_nodes + (node << 5); }
+PT_DEV uint32_t walk_lds_node(uint32_t lds_nodes, uint32_t state) { return state == 0xFFFFu ? PT_END : (state - lds_nodes) >> 5; }
+
+// one box phase in terms of node indices (the tile / persistent / split kernels)
+PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, uint32_t& leaf_count, uint32_t walk_min = 1u)
+{
+  uint32_t state = walk_lds_state(lds_nodes, w.node);
+  walk_to_leaf_lds_state(state, walk_lds_link_offset(w), w, leaf_first, leaf_count, walk_min);
+  w.node = walk_lds_node(lds_nodes, state);
 }
 
 template <bool STATS>
@@ -454,7 +463,7 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
     const float4 la = p.lights[l * 2 + 0], lb = p.lights[l * 2 + 1];
     hit.light = (int)l;
     hit.diffuse_col = mk3(la.x, la.y, la.z);
-    hit.normal = normalize(mk3(la.w, lb.x, lb.y) - (n.t * d)); // intersection.cuh:208: origin ignored
+    hit.normal = normalize_hot(mk3(la.w, lb.x, lb.y) - (n.t * d)); // intersection.cuh:208: origin ignored
     return hit.dist < PT_MAX_DIST;
   }
   // one burst of six independent 16-byte loads: geometry, material and the diffuse+specular map of the face (the
@@ -465,10 +474,14 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
   const float u = n.u, v = n.v;
   const float w = 1.0f - u - v;
   const f3 surface_normal = w * n0 + u * n1 + v * n2;
-  const float ux = w * s2.y + u * s2.w + v * s3.y;
-  const float uy = w * s2.z + u * s3.x + v * s3.z;
-  const float uvx = ux - __builtin_floorf(ux / 1.0f); // mod(uv, 1.0): cutils_math.h:1728-1737
-  const float uvy = uy - __builtin_floorf(uy / 1.0f);
+  // texture coordinates: only faces with a real texture or a normal map need them (none of indoor.obj's do), so they are
+  // computed where they are used
+  auto tex_uv = [&](float& uvx, float& uvy) {
+    const float ux = w * s2.y + u * s2.w + v * s3.y;
+    const float uy = w * s2.z + u * s3.x + v * s3.z;
+    uvx = ux - __builtin_floorf(ux / 1.0f); // mod(uv, 1.0): cutils_math.h:1728-1737
+    uvy = uy - __builtin_floorf(uy / 1.0f);
+  };
   const f3 tangent = mk3(s3.w, s4.x, s4.y);
   hit.normal = surface_normal;
   hit.light = -1;
@@ -480,6 +493,8 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
   } else {
     TexDesc tex;
     tex.w = (int32_t)f_as_u(s5.x); tex.h = (int32_t)f_as_u(s5.y); tex.nb_chan = (int32_t)f_as_u(s5.z); tex.pad = 0; tex.offset = f_as_u(s5.w);
+    float uvx, uvy;
+    tex_uv(uvx, uvy);
     const float* texel = PT_KARG(p, texels) + tex.offset + texture_idx(tex, uvx, uvy);
     hit.diffuse_col = mk3(texel[0], texel[1], texel[2]);
     hit.specular_col = texel[3];
@@ -489,6 +504,8 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
     const float4 s6 = sh[6];
     TexDesc nt;
     nt.w = (int32_t)f_as_u(s6.x); nt.h = (int32_t)f_as_u(s6.y); nt.nb_chan = (int32_t)f_as_u(s6.z); nt.pad = 0; nt.offset = f_as_u(s6.w);
+    float uvx, uvy;
+    tex_uv(uvx, uvy);
     const float* nx = PT_KARG(p, texels) + nt.offset + texture_idx(nt, uvx, uvy);
     const f3 nn = normalize((mk3(nx[0], nx[1], nx[2]) * 2.0f) - 1.0f);
     const f3 binormal = normalize(cross(tangent, surface_normal));
@@ -588,7 +605,7 @@ PT_DEV void path_begin(const KParams& p, uint32_t x, uint32_t y, Path& st, uint3
   // generateRay (intersection.cuh:75-97), pixel-invariant terms precomputed on the host
   const int half_w = (int)(width / 2u), half_h = (int)(PT_KARG(p, height) / 2u);
   const f3 screen_pos = (cam_p0 + (cam_u * (float)((int)x - half_w))) + (cam_v * (float)((int)y - half_h));
-  f3 dir = normalize(screen_pos - cam_pos);
+  f3 dir = normalize_hot(screen_pos - cam_pos);
   f3 origin = cam_pos;
 
   // camera_dof (post_process.cuh:49-67)
@@ -598,7 +615,7 @@ PT_DEV void path_begin(const KParams& p, uint32_t x, uint32_t y, Path& st, uint3
   float sn, cs;
   pt_sincosf(random_angle, sn, cs);
   const f3 ap = (cs * cam_u + sn * cam_v) * random_radius;
-  st.d = normalize(focal_point - ap);
+  st.d = normalize_hot(focal_point - ap);
   st.o = origin + ap;
 
   st.throughput = mk3(1.0f);
@@ -1071,12 +1088,23 @@ PT_DEV void traverse_round(const float4* nodes, const float4* tris, uint32_t n_n
   if (t_eff < 1u) t_eff = 1u;
   if (STATS) w.alive = (uint32_t)__popcll(__ballot(1));
   const uint32_t lds_nodes = (uint32_t)(uintptr_t)nodes;
-  for (;;) {
-    uint32_t leaf_first, leaf_count;
-    if (NODES_IN_LDS && !STATS && PT_ASM_WALK) walk_to_leaf_lds(lds_nodes, w, leaf_first, leaf_count, walk_min);
-    else walk_to_leaf<STATS>(nodes, w, leaf_first, leaf_count, cnt.nodes, cnt.wave_node_iters, walk_min);
-    if (leaf_count != 0u) walk_leaf<STATS>(tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters, small_det);
-    if ((uint32_t)__popcll(__ballot(w.node != PT_END)) < t_eff) break;
+  if (NODES_IN_LDS && !STATS && PT_ASM_WALK) {
+    uint32_t state = walk_lds_state(lds_nodes, w.node);
+    const uint32_t lnk = walk_lds_link_offset(w);
+    for (;;) {
+      uint32_t leaf_first, leaf_count;
+      walk_to_leaf_lds_state(state, lnk, w, leaf_first, leaf_count, walk_min);
+      if (leaf_count != 0u) walk_leaf<STATS>(tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters, small_det);
+      if ((uint32_t)__popcll(__ballot(state != 0xFFFFu)) < t_eff) break;
+    }
+    w.node = walk_lds_node(lds_nodes, state);
+  } else {
+    for (;;) {
+      uint32_t leaf_first, leaf_count;
+      walk_to_leaf<STATS>(nodes, w, leaf_first, leaf_count, cnt.nodes, cnt.wave_node_iters, walk_min);
+      if (leaf_count != 0u) walk_leaf<STATS>(tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters, small_det);
+      if ((uint32_t)__popcll(__ballot(w.node != PT_END)) < t_eff) break;
+    }
   }
   best = w.best;
   node = w.node;
