@@ -521,7 +521,9 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
 // texCubemap restated (see oracle/pt_oracle.c: or_tex_cubemap for the definition)
 PT_DEV f3 env_lookup(const KParams& p, f3 dir)
 {
-  const float x = dir.x, y = dir.y, z = -dir.z; // raytrace.cu:60,197
+  float x = dir.x, y = dir.y, z = -dir.z; // raytrace.cu:60,197
+  // (the compiler otherwise computes |dir| where the walk is set up, for both uses, and spills it across the walk)
+  asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
   const uint32_t n = PT_KARG(p, cubemap_size);
   const float4* cubemap = PT_KARG(p, cubemap);
   const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
@@ -1323,7 +1325,6 @@ pt_megakernel_restart(const KParams p)
   Best best;
   best.t = PT_MAX_DIST; best.u = best.v = 0.f; best.idx = PT_END;
   uint32_t node = PT_END;
-  float r1 = 0.f;
   // wave-uniform: the pool holds the paths of ONE tile, entries [pool_rd, 64) not yet handed out
   uint32_t pool_rd = 64u, tile_x0 = 0, tile_y0 = 0, tile_k = 0;
   uint32_t tile_row_delta = 0;   // (frame row) - (row of the launch's buffers + row_begin): non-zero for interleaved bands
@@ -1420,7 +1421,6 @@ pt_megakernel_restart(const KParams p)
 
     if (!idle) {
       if (!walking) {
-        r1 = path_pre(p, st);
         best.t = PT_MAX_DIST; best.u = 0.f; best.v = 0.f; best.idx = PT_END;
         node = p.n_nodes ? 0u : PT_END;
         cur = p.n_nodes4 ? 0u : PT_NONE;
@@ -1439,6 +1439,9 @@ pt_megakernel_restart(const KParams p)
         if (node == PT_END) cnt.fetch_rays++;
       }
       if (node == PT_END) {
+        // the iteration's first variate (raytrace.cu:70) is drawn here, after the search: intersect() draws nothing, so the
+        // path's random stream is the same, and r1 need not live (in scratch, as it turned out) across the walk
+        const float r1 = path_pre(p, st);
         Nearest n;
         n.t = best.t; n.u = best.u; n.v = best.v; n.idx = best.idx;
         n = nearest_lights(p, st.o, st.d, n);

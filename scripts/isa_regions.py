@@ -7,9 +7,9 @@ import os, re, subprocess, sys, tempfile, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cuda-pathtracer_amd", "csrc", "pt_kernels.hip")
 MARKS = [  # (unique source anchor, marker name) — the marker goes in front of the anchor
-    ("    if (!idle) {\n      if (!walking) {\n        r1 = path_pre(p, st);", "round_begin"),
+    ("    if (!idle) {\n      if (!walking) {\n        best.t = PT_MAX_DIST;", "round_begin"),
     ("      if (WIDE) {\n        traverse_round4<STATS>(p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min", "traverse_begin"),
-    ("      if (node == PT_END) {\n        Nearest n;\n        n.t = best.t; n.u = best.u; n.v = best.v; n.idx = best.idx;\n        n = nearest_lights(p, st.o, st.d, n);\n        walking = false;", "traverse_end"),
+    ("      if (node == PT_END) {\n        // the iteration's first variate", "traverse_end"),
     ("        walking = false;\n        if (path_post<STATS>(p, st, r1, n, cnt)) {", "lights_end"),
     ("          path_finish_sample(p, st);\n          idle = true;\n          if (STATS) samples++;", "post_end"),
     ("  if (!p.is_static) {\n    st.acc = found ? inter.diffuse_col : env_lookup(p, st.d);", "resolve_end"),
