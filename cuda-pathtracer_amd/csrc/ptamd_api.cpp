@@ -78,7 +78,7 @@ struct ptamd_context {
   // restart kernel: a round of walks ends once fewer than min(round_min, entering lanes / round_div) lanes are unfinished
   // measured (scripts/gpu_r2_sweep.sh, 1080p x 4 spp x 4 bounces): round_min 16-32 and walk_min 4-6 are a flat optimum
   uint32_t round_min = 16, round_div = 4; // PTAMD_ROUND_MIN, PTAMD_ROUND_DIV
-  uint32_t walk_min = 5;                  // restart kernel: a box phase ends once fewer lanes than this still walk (PTAMD_WALK_MIN)
+  uint32_t walk_min = 7;                  // restart kernel: a box phase ends once fewer lanes than this still walk (PTAMD_WALK_MIN; 4 / 5 / 7 / 8 / 10 / 12: 9331 / 9372 / 9405 / 9377 / 9338 / 9273 Msamples/s with the final shading code)
   bool pool_in_lds = true;                // restart kernel: pools of fresh paths in LDS when they fit (PTAMD_POOL_LDS=0: always the global slab)
   uint32_t treelet_nodes = 512;           // wide walk: nodes of the top of the tree staged in LDS (PTAMD_TREELET; with LDS pools 341 / 512 / 640: 1286 / 1291 / 1275)
   uint32_t walk_min4 = 16;                // the same threshold for the four-wide walk (PTAMD_WALK_MIN4; 1/4/8/16/24: 813/902/960/994/971 Msamples/s)
