@@ -313,6 +313,7 @@ struct Hit {
   float specular_col; // carried over between iterations on light hits
   float ior;
   int light;          // -1 none
+  float emission;     // light hits: the light's emission (its colour is diffuse_col)
 };
 
 } // namespace ptamd

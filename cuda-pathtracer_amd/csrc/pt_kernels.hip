@@ -462,6 +462,7 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
     const uint32_t l = n.idx & ~PT_LIGHT;
     const float4 la = p.lights[l * 2 + 0], lb = p.lights[l * 2 + 1];
     hit.light = (int)l;
+    hit.emission = lb.z;
     hit.diffuse_col = mk3(la.x, la.y, la.z);
     hit.normal = normalize_hot(mk3(la.w, lb.x, lb.y) - (n.t * d)); // intersection.cuh:208: origin ignored
     return hit.dist < PT_MAX_DIST;
@@ -642,7 +643,7 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
 {
   Hit inter;
   inter.normal = mk3(0.f); inter.diffuse_col = mk3(0.f);
-  inter.dist = 0.f; inter.specular_col = st.specular_col; inter.ior = 0.f; inter.light = -1;
+  inter.dist = 0.f; inter.specular_col = st.specular_col; inter.ior = 0.f; inter.light = -1; inter.emission = 0.f;
   const bool found = resolve_hit<STATS>(p, st.d, nearest, inter, cnt);
 
   if (!p.is_static) {
@@ -676,8 +677,8 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
   const f3 direct_light = inter.diffuse_col / 0.5f; // brdf_lambert / pdf_lambert (brdf.cuh:14-31)
   if (inter.ior == 1.0f || inter.light >= 0) {
     if (inter.light >= 0) {
-      const float4 la = p.lights[inter.light * 2 + 0], lb = p.lights[inter.light * 2 + 1];
-      st.acc = st.acc + (mk3(la.x, la.y, la.z) * lb.z) * st.throughput;
+      // raytrace.cu:86: (light colour * emission) * throughput; resolve_hit has both in registers (no second fetch of the record)
+      st.acc = st.acc + (inter.diffuse_col * inter.emission) * st.throughput;
     }
     const float phi = (float)((double)2.0f * 3.14159265358979323846 * (double)xorwow_uniform(st.rng));
     // r1 is a uniform variate in (0, 1] (or 0): both arguments are 0 or >= 2^-33
