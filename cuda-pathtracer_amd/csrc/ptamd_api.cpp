@@ -239,9 +239,11 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   const bool resident = lds <= kLdsBudget && (kind == 1 || s.n_nodes <= kCompactMaxNodes);
   // PTAMD_KERNEL_AUTO, one frame per launch (the reference's interactive loop, ptamd_raytrace) on an LDS-resident scene:
   // the persistent kernel writes the surface itself, the restart kernel would add its resolve pass to every launch
-  // (1080p, one launch per spp: 5.79 vs 5.27 Gsamples/s).  Batched frames, big scenes and interleaved bands: restart.
+  // (1080p, one launch per spp, one at a time: 6.03 vs 5.89 Gsamples/s).  A caller that keeps several such launches in
+  // flight (machine_share > 1) gets the restart kernel (two in flight: 7.92 vs 6.97), as do batched frames, big scenes
+  // and interleaved bands.
   if (l->kernel == PTAMD_KERNEL_AUTO && which == PTAMD_KERNEL_BVH_RESTART && ctx->default_kernel_is_builtin && l->frame_count <= 1 &&
-      resident && l->interleave_ranks <= 1)
+      resident && l->interleave_ranks <= 1 && l->machine_share <= 1)
     which = PTAMD_KERNEL_BVH_PERSISTENT;
   hipStream_t stream = static_cast<hipStream_t>(l->stream);
   hipError_t e;
