@@ -397,9 +397,11 @@ PT_DEV ConstF as_constant(const float4* q) { return (ConstF)(uintptr_t)q; }
 template <typename T>
 PT_DEV T karg_load(uint32_t byte_offset)
 {
-  const __attribute__((address_space(4))) char* q = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset;
+  // the barrier sits on the segment pointer, not on the field's address: every use is then `s_load ..., base, offset` off
+  // ONE scalar pair instead of a hoisted (and spilled) address pair per field
+  const __attribute__((address_space(4))) char* q = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(q));
-  return *(const __attribute__((address_space(4))) T*)q;
+  return *(const __attribute__((address_space(4))) T*)(q + byte_offset);
 }
 #ifndef PT_KARG_ALL
 #define PT_KARG_ALL 1
