@@ -83,6 +83,12 @@ PT_DEV float rcp_hot(float x)
   if (PT_SHORT_MATH && wave_all(x >= 0x1p-95f && x <= 0x1p125f)) return rcp_exact_in_range(x);
   return 1.0f / x;
 }
+// sqrtf(x) for a non-negative (or NaN) x that is usually 0 or >= 2^-96
+PT_DEV float sqrt_checked(float x)
+{
+  if (PT_SHORT_MATH && wave_all(!(x < 0x1p-96f) || x == 0.0f)) return sqrt_exact_in_range(x);
+  return __builtin_sqrtf(x);
+}
 // sqrtf(x) for an x known to be 0 or >= 2^-96 (a uniform variate, 1 - a uniform variate)
 PT_DEV float sqrt_hot(float x) { return PT_SHORT_MATH ? sqrt_exact_in_range(x) : __builtin_sqrtf(x); }
 // cutils_math.h:1678

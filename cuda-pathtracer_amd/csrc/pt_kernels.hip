@@ -360,7 +360,7 @@ PT_DEV bool intersect_sphere(f3 o, f3 d, f3 center, float radius, float& t)
   const float b = dot(op, d);
   float disc = b * b - dot(op, op) + radius * radius;
   if (disc < 0.0f) return false;
-  disc = __builtin_sqrtf(disc);
+  disc = sqrt_checked(disc);
   t = b - disc;
   if (!(t > epsilon)) t = b + disc;
   return t != 0.0f;
