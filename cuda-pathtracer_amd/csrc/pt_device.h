@@ -299,6 +299,10 @@ struct KParams {
   uint32_t round_min, round_div;
   uint32_t walk_min;   // a box phase ends once fewer lanes than this are still walking (1: when none is)
   uint32_t small_det;  // != 0: the scene's coordinates are <= 1e8, so Moller-Trumbore determinants stay below 2^125
+  // != 0: the environment is one colour (a 1x1 cubemap whose six texels are bit-identical — what the reference ends up
+  // with when its cubemap image does not load): texCubemap returns env_color whatever the direction, no lookup
+  uint32_t env_uniform;
+  float env_r, env_g, env_b;
   // four-wide walk (scenes that do not fit in LDS): 8 float4 per node, per-lane stacks in LDS with a global continuation
   const float4* nodes4;
   uint32_t n_nodes4;

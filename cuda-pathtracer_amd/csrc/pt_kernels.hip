@@ -524,6 +524,8 @@ PT_DEV bool resolve_hit(const KParams& p, f3 d, Nearest n, Hit& hit, Counters& c
 // texCubemap restated (see oracle/pt_oracle.c: or_tex_cubemap for the definition)
 PT_DEV f3 env_lookup(const KParams& p, f3 dir)
 {
+  // one-colour environment (flag set by the host, ptamd_upload_cubemap): the face choice below cannot matter
+  if (PT_KARG(p, env_uniform)) return mk3(PT_KARG(p, env_r), PT_KARG(p, env_g), PT_KARG(p, env_b));
   float x = dir.x, y = dir.y, z = -dir.z; // raytrace.cu:60,197
   // (the compiler otherwise computes |dir| where the walk is set up, for both uses, and spills it across the walk)
   asm volatile("" : "+v"(x), "+v"(y), "+v"(z));

@@ -47,6 +47,8 @@ struct DeviceScene {
 struct DeviceCubemap {
   float4* faces = nullptr;
   uint32_t size = 0;
+  bool uniform = false;     // size 1 and the six texels' rgb bit-identical: every lookup returns color
+  float color[3] = { 0.f, 0.f, 0.f };
 };
 
 } // namespace
@@ -189,6 +191,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   p.nodes = s.nodes; p.tris_bvh = s.tris_bvh; p.tris_brute = s.tris_brute; p.shade = s.shade;
   p.materials = s.materials; p.lights = s.lights; p.textures = s.textures; p.texels = s.texels;
   p.cubemap = cm.faces; p.cubemap_size = cm.size;
+  p.env_uniform = cm.uniform ? 1u : 0u; p.env_r = cm.color[0]; p.env_g = cm.color[1]; p.env_b = cm.color[2];
   p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
   p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4;
   // finite edges of at most 2e8 per axis and unit directions: det = e1 . (dir x e2) is far below 2^125 (or NaN, which
@@ -659,6 +662,11 @@ int ptamd_upload_cubemap(ptamd_context* ctx, const float* faces, uint32_t size, 
   PT_HIP(hipSetDevice(ctx->device));
   DeviceCubemap c;
   c.size = size;
+  if (size == 1) {
+    c.uniform = true;
+    for (int f = 1; f < 6; ++f) c.uniform = c.uniform && std::memcmp(faces + f * 4, faces, 12) == 0;
+    std::memcpy(c.color, faces, 12);
+  }
   int rc = upload(c.faces, faces, (size_t)6 * size * size * 16);
   if (rc != PTAMD_OK) return rc;
   ctx->cubemaps.push_back(c);

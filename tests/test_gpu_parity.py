@@ -649,6 +649,26 @@ def test_scene_with_huge_coordinates(P, O, gpu_ctx):
         assert_same(acc, rgba, *ref, f"far scene/{kernel}")
 
 
+def test_one_texel_cubemaps(P, O, gpu_ctx):
+    """1x1 cubemaps: six different texels (the face choice matters), six identical ones (the launcher's one-colour shortcut:
+    env_lookup returns the colour without a lookup), identical rgb with different alpha (still one colour), and rgb that differs
+    only in the sign of a zero (NOT one colour: bit patterns decide) — static and preview launches, every kernel variant."""
+    rng = np.random.default_rng(91)
+    lights = [((0.0, 0.5, 1.0), (1.0, 0.9, 0.8), 4.0, 0.8)]
+    hs = make_scene(P, random_soup(rng, 30, extent=1.5, size=0.7), lights=lights)      # sparse: many rays escape
+    six = synthetic_cubemap(rng, 1)
+    same = np.repeat(six[:1], 6, axis=0).copy()
+    same_alpha = same.copy(); same_alpha[:, 0, 0, 3] = np.arange(6, dtype=np.float32)
+    zero_sign = same.copy(); zero_sign[:, 0, 0, 1] = 0.0; zero_sign[3, 0, 0, 1] = -0.0
+    for name, cube in (("six texels", six), ("one colour", same), ("one colour, alpha differs", same_alpha), ("zero of either sign", zero_sign)):
+        for moved in (False, True):
+            ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 48, 32, spp=2, bounces=4, moved=moved)
+            assert (ref[0] > 0).any()
+            for kernel in KERNELS:
+                acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 48, 32, 2, 4, kid(P, kernel), moved=moved)
+                assert_same(acc, rgba, *ref, f"{name}/moved={moved}/{kernel}")
+
+
 def test_scenes_outside_the_short_reciprocal_range(P, O, gpu_ctx):
     """The restart kernel divides by the Moller-Trumbore determinant with a 7-instruction exact reciprocal only where the
     launcher can bound the determinant (all vertices finite and <= 1e8, ptamd_api.cpp: small_det).  One far vertex (3e9), an
