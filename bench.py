@@ -73,8 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate HIP streams, each with its own buffers (double "
                          "buffering, as the reference double-buffers its GL renderbuffers: driver/interop.cpp:107-111).  "
-                         "0 = auto: 4 (on several GPUs the RCCL all-gather of frame i overlaps the render of the next ones); "
-                         "each launch is sized to 1/n of the GPU (ptamd_launch.machine_share)")
+                         "0 = auto: 2 on one GPU, 4 on several GPUs (the RCCL all-gather of frame i overlaps the render of "
+                         "the next ones); each launch is sized to 1/n of the GPU (ptamd_launch.machine_share)")
     ap.add_argument("--no-share", dest="share", action="store_false",
                     help="with several frames in flight, size every launch to the whole GPU instead of its 1/n share")
     ap.add_argument("--sequential", action="store_true", help="one launch per spp instead of one batched launch per frame")
@@ -357,8 +357,10 @@ def main():
         hs.camera["aperture"] = args.aperture
     cube = P.cubemap_for_scene(hs)
     # measured on one rank's share of an 8-way split (scripts/band_proxy.py): 3 / 4 / 5 frames in flight = 0.166 / 0.155 / 0.183 ms
-    # whole frame on one GPU, last build of round 2 (scripts/gpu_fif.sh): 2 / 3 / 4 in flight = 9927 / 9930 / 10031 Msamples/s
-    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else 4
+    # whole frame on one GPU, last build of round 2: 2 / 3 / 4 in flight = 9927 / 9930 / 10031 Msamples/s over 60 steps
+    # (scripts/gpu_fif.sh) but 9815 / 9660 / 9590 over the 20 steps the driver times: the deeper pipeline drains longer at the
+    # end of the timed region than it gains in steady state
+    n_slots = args.frames_in_flight if args.frames_in_flight > 0 else (4 if (world > 1 or args.as_rank is not None) else 2)
     gather = world > 1 or force_gather
 
     rows = None
