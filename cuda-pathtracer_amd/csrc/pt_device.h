@@ -255,7 +255,7 @@ struct KParams {
   const float4* tris_brute; // 3 float4 per triangle, storage order
   const float4* shade;      // 7 float4 per face, storage order: n0 n1 n2 | uv0 uv1 uv2 | tangent | material id, ior | diffuse map desc | normal map desc
   const int4* materials;    // {diffuse_spec_map, normal_map, bits(ior), 0}
-  const float4* lights;     // 2 float4 per light: {color.xyz, vec.x} {vec.y, vec.z, emission, radius}
+  const float4* lights;     // 2 float4 per light: {color.xyz, vec.x} {vec.y, vec.z, emission, radius^2}
   const TexDesc* textures;
   const float* texels;
   const float4* cubemap;    // 6 * size * size

@@ -353,12 +353,12 @@ PT_DEV void traverse_bvh(const float4* nodes, const float4* tris, uint32_t n_nod
 }
 
 // intersection.cuh:140-155 (see the oracle's note on the discarded conditional at :152)
-PT_DEV bool intersect_sphere(f3 o, f3 d, f3 center, float radius, float& t)
+PT_DEV bool intersect_sphere(f3 o, f3 d, f3 center, float radius2 /* radius * radius, formed by the host */, float& t)
 {
   const float epsilon = 0.01f;
   const f3 op = center - o;
   const float b = dot(op, d);
-  float disc = b * b - dot(op, op) + radius * radius;
+  float disc = b * b - dot(op, op) + radius2;
   if (disc < 0.0f) return false;
   disc = sqrt_checked(disc);
   t = b - disc;
@@ -417,7 +417,7 @@ PT_DEV T karg_load(uint32_t byte_offset)
 
 PT_DEV Nearest nearest_lights(const KParams& p, f3 o, f3 d, Nearest n)
 {
-  const ConstF lights = as_constant(p.lights);     // 8 floats per light: color.xyz, vec.xyz, emission, radius
+  const ConstF lights = as_constant(p.lights);     // 8 floats per light: color.xyz, vec.xyz, emission, radius^2 (ptamd_api.cpp)
   for (uint32_t l = 0; l < p.n_lights; ++l) {
     const ConstF L = lights + l * 8u;
     // the discriminant of intersect_sphere, same operations: when it is negative for every lane of the wave (the usual
@@ -425,7 +425,7 @@ PT_DEV Nearest nearest_lights(const KParams& p, f3 o, f3 d, Nearest n)
     const f3 c = mk3(L[3], L[4], L[5]);
     const f3 op = c - o;
     const float b = dot(op, d);
-    const float disc = b * b - dot(op, op) + L[7] * L[7];
+    const float disc = b * b - dot(op, op) + L[7];
     if (__builtin_amdgcn_ballot_w64(!(disc < 0.0f)) == 0ull) continue;
     float t;
     if (intersect_sphere(o, d, c, L[7], t) && t < n.t && t >= 0.0f) {

@@ -633,13 +633,17 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   d.extent = bvh.extent; d.all_finite = bvh.all_finite; d.margin_floor = bvh.margin_floor;
   d.n_nodes4 = bvh.n_nodes4; d.depth4 = bvh.depth4;
   d.n_materials = sc->n_materials; d.n_textures = sc->n_textures;
+  // device copy of the lights: the radius only ever enters as radius * radius (intersection.cuh:147) — the same binary32
+  // product whoever forms it — so the table carries the square in its place and every sphere test saves the multiply
+  std::vector<ptamd_light> dev_lights(sc->lights, sc->lights + sc->n_lights);
+  for (ptamd_light& dl : dev_lights) dl.radius = dl.radius * dl.radius;
   if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
       (rc = upload(d.nodes4, bvh.nodes4.data(), bvh.nodes4.size() * 4)) ||
       (rc = upload(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4)) ||
       (rc = upload(d.tris_brute, brute.data(), brute.size() * 4)) ||
       (rc = upload(d.shade, shade.data(), shade.size() * 4)) ||
       (rc = upload(d.materials, mats.data(), mats.size() * 4)) ||
-      (rc = upload(d.lights, sc->lights, (size_t)sc->n_lights * sizeof(ptamd_light))) ||
+      (rc = upload(d.lights, dev_lights.data(), dev_lights.size() * sizeof(ptamd_light))) ||
       (rc = upload(d.textures, tex.data(), tex.size() * sizeof(TexDesc))) ||
       (rc = upload(d.texels, sc->texels, (size_t)sc->n_texel_floats * 4))) {
     free_scene(d);
