@@ -12,7 +12,7 @@ import sys, glob, csv, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
-    if "restart" in r["Kernel_Name"]:
+    if "restart<true, false>" in r["Kernel_Name"]:      # the un-instrumented batched dispatches (not the STATS launches of the bench)
         acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
 for c, d in acc.items():
     print("  %s per launch: %.0f (%d dispatches)" % (c, sum(d.values()) / len(d), len(d)))
