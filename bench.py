@@ -284,10 +284,12 @@ class Workload:
                                 "wave_node_iters", "idle_unstarted", "idle_finished", "idle_parked")}
         scratch = P.FrameRenderer(self.ctx, self.sid, self.cid, self.hs.camera_struct(), self.W, self.H,
                                   rows=(self.y0, self.y1), band_local=True, interleave=self.interleave)
-        for k in range(1, self.spp + 1):
+        # the same launches as the timed ones: one batched launch of spp frames, or spp single-frame launches
+        per_launch = self.frames_per_launch
+        for k in range(1, self.spp + 1, per_launch):
             l = self.ctx.make_launch(scratch.surface, scratch.accum, self.sid, self.cid, self.hs.camera_struct(), self.W,
                                      self.H, frame_nb=k, bounces=self.B, rows=scratch.rows, kernel=self.kernel,
-                                     band_local_buffers=True, interleave=self.interleave)
+                                     band_local_buffers=True, interleave=self.interleave, frame_count=per_launch)
             s = self.ctx.raytrace_stats(l)
             for key in stats:
                 stats[key] += s[key]
