@@ -303,6 +303,10 @@ struct KParams {
   // with when its cubemap image does not load): texCubemap returns env_color whatever the direction, no lookup
   uint32_t env_uniform;
   float env_r, env_g, env_b;
+  // 258 floats built once per context (pt_build_gamma_table): T[j], j = 1..255, is the smallest x whose surface byte
+  // pt_f2u(pt_powf(x, 1/2.2) * 255) reaches j, T[0] = 0, T[256] the smallest x whose value reaches 256 (from there on the
+  // resolve pass evaluates pt_powf as before).  nullptr: no table, pt_powf everywhere.
+  const float* gamma_table;
   // four-wide walk (scenes that do not fit in LDS): 8 float4 per node, per-lane stacks in LDS with a global continuation
   const float4* nodes4;
   uint32_t n_nodes4;

@@ -785,6 +785,36 @@ PT_DEV bool path_step(const KParams& p, const float4* s_nodes, const float4* s_t
   return path_post<STATS>(p, st, r1, n, cnt);
 }
 
+// ---------------------------------------------------------------- the gamma step of the tonemap as a table
+//
+// raytrace.cu:262-268: colour = pow(colour, 1/2.2), then each channel * 255 is stored through a truncating conversion.  With
+// no post-process in between, the stored byte is a monotone step function of the value going into pow, and pt_powf — the
+// build's binary64 definition of powf, ~70 instructions, 50 of them f64 — is by far the dearest thing the resolve pass does
+// (three per pixel).  The 256 steps are found once per context with pt_powf itself (pt_build_gamma_table, a binary search
+// over bit patterns per step) and the byte is read off them: a 3-instruction estimate (v_log, v_mul, v_exp) that is
+// within one step of the answer, corrected by two comparisons against the table.  ptamd_gamma_table_selftest compares the
+// result with the pt_powf form for EVERY binary32 value below T[256] on the device.
+PT_DEV uint32_t gamma_byte_exact(float x)   // the definition (post_id 0): what the reference's store sequence produces
+{
+  return pt_f2u(pt_powf(x, 1.0f / 2.2f) * 255.0f) & 0xffu;
+}
+PT_DEV uint32_t gamma_value_exact(float x) { return pt_f2u(pt_powf(x, 1.0f / 2.2f) * 255.0f); }
+
+// T points at 258 floats (LDS copy in the resolve kernels).  Valid for every x: values at or above T[256], and NaN, take the
+// pt_powf form; negative values and zero give 0 either way (pt_powf: NaN or 0 -> pt_f2u -> 0).
+template <typename TablePtr>
+PT_DEV uint32_t gamma_byte(float x, TablePtr T)
+{
+  if (!(x < T[256])) return gamma_byte_exact(x);
+  if (!(x > 0.0f)) return 0u;
+  const float est = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (1.0f / 2.2f)) * 255.0f;
+  int k = (int)est;
+  k = k < 0 ? 0 : (k > 255 ? 255 : k);
+  k = x < T[k] ? k - 1 : k;          // T[0] = 0 < x: k stays >= 0
+  k = x >= T[k + 1] ? k + 1 : k;     // x < T[256]: k stays <= 255
+  return (uint32_t)k;
+}
+
 // kernel() epilogue: clamp, temporal accumulation, tonemap, gamma, post-process, RGBA8 store
 // (raytrace.cu:248-270)
 PT_DEV void path_finish(const KParams& p, const Path& st)
@@ -800,11 +830,15 @@ PT_DEV void path_finish(const KParams& p, const Path& st)
   tp[0] = t.x; tp[1] = t.y; tp[2] = t.z;
   rad = t / p.frame_nb_f;
   rad = exposure(rad);
-  const float g = 1.0f / 2.2f;
-  rad = mk3(pt_powf(rad.x, g), pt_powf(rad.y, g), pt_powf(rad.z, g));
-  rad = post_process(p.post_id, rad);
-  const uint32_t px = (pt_f2u(rad.x * 255.0f) & 0xffu) | ((pt_f2u(rad.y * 255.0f) & 0xffu) << 8) |
-                      ((pt_f2u(rad.z * 255.0f) & 0xffu) << 16);
+  uint32_t px;
+  if (p.gamma_table && p.post_id == 0u) {   // the byte read off the gamma table (two loads per channel) instead of three pt_powf
+    px = gamma_byte(rad.x, p.gamma_table) | (gamma_byte(rad.y, p.gamma_table) << 8) | (gamma_byte(rad.z, p.gamma_table) << 16);
+  } else {
+    const float g = 1.0f / 2.2f;
+    rad = mk3(pt_powf(rad.x, g), pt_powf(rad.y, g), pt_powf(rad.z, g));
+    rad = post_process(p.post_id, rad);
+    px = (pt_f2u(rad.x * 255.0f) & 0xffu) | ((pt_f2u(rad.y * 255.0f) & 0xffu) << 8) | ((pt_f2u(rad.z * 255.0f) & 0xffu) << 16);
+  }
   p.surface[(size_t)(y - p.surf_row0) * p.width + x] = px;
 }
 
@@ -1799,6 +1833,36 @@ __global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakern
   flush_counters<STATS>(p, cnt, samples);
 }
 
+// ---------------------------------------------------------------- gamma table: construction and exhaustive check
+
+// thread j (1..256) finds T[j]: the smallest non-negative binary32 x (by bit pattern) with gamma_value_exact(x) >= j
+__global__ void __launch_bounds__(320) pt_build_gamma_table(float* T)
+{
+  const uint32_t j = threadIdx.x;
+  if (j > 256u) return;
+  if (j == 0u) { T[0] = 0.0f; T[257] = 0.0f; return; }
+  uint32_t lo = 0u, hi = 0x7F800000u;          // value(lo) < j <= value(hi): +0 gives 0, +inf saturates
+  while (hi - lo > 1u) {
+    const uint32_t mid = lo + (hi - lo) / 2u;
+    if (gamma_value_exact(u_as_f(mid)) >= j) hi = mid; else lo = mid;
+  }
+  T[j] = u_as_f(hi);
+}
+
+// every positive binary32 below T[256] (bit patterns first .. first + count - 1): table form against the pt_powf form
+__global__ void __launch_bounds__(256) pt_gamma_selftest(const float* T, uint32_t first, uint32_t count, unsigned long long* out)
+{
+  __shared__ float s_T[258];
+  for (uint32_t i = threadIdx.x; i < 258u; i += 256u) s_T[i] = T[i];
+  __syncthreads();
+  unsigned long long bad = 0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+    const float x = u_as_f(first + i);
+    if (gamma_byte(x, s_T) != gamma_byte_exact(x)) ++bad;
+  }
+  if (bad) atomicAdd(out, bad);
+}
+
 // Second kernel of a batched launch: per pixel, apply the parked samples to the temporal
 // framebuffer in frame order — t = t * is_static + s_k for k = 0..count-1, exactly what `count`
 // consecutive launches do (raytrace.cu:255-256, is_static == 1) — then tonemap once with the last
@@ -1823,11 +1887,15 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel(const KParams p)
   tp[0] = t.x; tp[1] = t.y; tp[2] = t.z;
   f3 rad = t / p.frame_nb_f; // (float)(frame_nb0 + count - 1)
   rad = exposure(rad);
-  const float g = 1.0f / 2.2f;
-  rad = mk3(pt_powf(rad.x, g), pt_powf(rad.y, g), pt_powf(rad.z, g));
-  rad = post_process(p.post_id, rad);
-  const uint32_t px = (pt_f2u(rad.x * 255.0f) & 0xffu) | ((pt_f2u(rad.y * 255.0f) & 0xffu) << 8) |
-                      ((pt_f2u(rad.z * 255.0f) & 0xffu) << 16);
+  uint32_t px;
+  if (p.gamma_table && p.post_id == 0u) {
+    px = gamma_byte(rad.x, p.gamma_table) | (gamma_byte(rad.y, p.gamma_table) << 8) | (gamma_byte(rad.z, p.gamma_table) << 16);
+  } else {
+    const float g = 1.0f / 2.2f;
+    rad = mk3(pt_powf(rad.x, g), pt_powf(rad.y, g), pt_powf(rad.z, g));
+    rad = post_process(p.post_id, rad);
+    px = (pt_f2u(rad.x * 255.0f) & 0xffu) | ((pt_f2u(rad.y * 255.0f) & 0xffu) << 8) | ((pt_f2u(rad.z * 255.0f) & 0xffu) << 16);
+  }
   p.surface[(size_t)(y - p.surf_row0) * p.width + x] = px;
 }
 
@@ -1838,6 +1906,12 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel4(const KParams p)
   // the ticket heads of this launch are spent (the megakernel has finished: stream order): leave them zeroed for the
   // launch that gets this slot of the ring next, instead of a memset in front of every launch
   if (blockIdx.x == 0 && threadIdx.x < 8u && p.tile_heads) p.tile_heads[threadIdx.x * PT_HEAD_STRIDE] = 0u;
+  __shared__ float s_gamma[258];
+  const bool use_table = p.gamma_table != nullptr && p.post_id == 0u;
+  if (use_table) {
+    for (uint32_t i = threadIdx.x; i < 258u; i += 256u) s_gamma[i] = p.gamma_table[i];
+    __syncthreads();
+  }
   const uint32_t rows = p.row_end - p.row_begin;
   const uint32_t groups_per_row = p.width / 4u;
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;
@@ -1861,6 +1935,10 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel4(const KParams p)
   for (int q = 0; q < 4; ++q) {
     f3 rad = mk3(t[q * 3 + 0], t[q * 3 + 1], t[q * 3 + 2]) / p.frame_nb_f;
     rad = exposure(rad);
+    if (use_table) {
+      px[q] = gamma_byte(rad.x, s_gamma) | (gamma_byte(rad.y, s_gamma) << 8) | (gamma_byte(rad.z, s_gamma) << 16);
+      continue;
+    }
     rad = mk3(pt_powf(rad.x, g22), pt_powf(rad.y, g22), pt_powf(rad.z, g22));
     rad = post_process(p.post_id, rad);
     px[q] = (pt_f2u(rad.x * 255.0f) & 0xffu) | ((pt_f2u(rad.y * 255.0f) & 0xffu) << 8) | ((pt_f2u(rad.z * 255.0f) & 0xffu) << 16);
@@ -2116,6 +2194,19 @@ hipError_t launch_resolve(const KParams& p, hipStream_t stream)
                     ((uintptr_t)p.surface % 16u) == 0u;
   if (wide) hipLaunchKernelGGL(pt_resolve_kernel4, dim3((n / 4u + 255u) / 256u), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(pt_resolve_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t build_gamma_table(float* table_dev, hipStream_t stream)
+{
+  hipLaunchKernelGGL(pt_build_gamma_table, dim3(1), dim3(320), 0, stream, table_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_gamma_selftest(const float* table_dev, uint32_t first, uint32_t count, unsigned long long* out_dev, hipStream_t stream)
+{
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(pt_gamma_selftest, dim3(4096), dim3(256), 0, stream, table_dev, first, count, out_dev);
   return hipGetLastError();
 }
 

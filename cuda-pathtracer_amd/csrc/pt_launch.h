@@ -27,6 +27,9 @@ hipError_t restart_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out);
 hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t lds_bytes, bool stats,
                                      uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_resolve(const KParams& p, hipStream_t stream);
+// gamma step of the tonemap as a table (pt_kernels.hip: gamma_byte): 258 floats, and its exhaustive check
+hipError_t build_gamma_table(float* table_dev, hipStream_t stream);
+hipError_t launch_gamma_selftest(const float* table_dev, uint32_t first, uint32_t count, unsigned long long* out_dev, hipStream_t stream);
 // Resolves every kernel entry point of the code object (setupFunctionTables' role: fail early when the device image is unusable).
 hipError_t resolve_kernels();
 hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,

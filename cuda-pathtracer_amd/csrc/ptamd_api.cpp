@@ -61,6 +61,7 @@ struct ptamd_context {
   std::vector<ptamd::DeviceCubemap> cubemaps;
   uint32_t frame_counter = 0; // raytrace.cu:296 `static unsigned int seed`
   unsigned long long* d_stats = nullptr;
+  float* d_gamma = nullptr;               // 258 floats: the gamma step of the tonemap as a table (pt_kernels.hip: gamma_byte); null with PTAMD_GAMMA_TABLE=0
   // persistent variant: ring of tile ticket counters (one per in-flight launch) and grid sizing
   uint32_t* d_tickets = nullptr;
   uint32_t* d_heads = nullptr;   // kTicketRing sets of 8 ticket heads, PT_HEAD_STRIDE dwords apart (persistent kernel)
@@ -192,6 +193,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   p.materials = s.materials; p.lights = s.lights; p.textures = s.textures; p.texels = s.texels;
   p.cubemap = cm.faces; p.cubemap_size = cm.size;
   p.env_uniform = cm.uniform ? 1u : 0u; p.env_r = cm.color[0]; p.env_g = cm.color[1]; p.env_b = cm.color[2];
+  p.gamma_table = ctx->d_gamma;
   p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
   p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4;
   // finite edges of at most 2e8 per axis and unit directions: det = e1 . (dir x e2) is far below 2^125 (or NaN, which
@@ -485,6 +487,15 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_heads), (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
   PT_HIP(hipMemset(ctx->d_heads, 0, (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
   ctx->heads_clean.assign(kTicketRing, true);
+  {
+    const char* e = std::getenv("PTAMD_GAMMA_TABLE"); // tuning knob: 0 = pt_powf for every pixel
+    if (!e || std::atoi(e) != 0) {
+      PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_gamma), 258 * sizeof(float)));
+      hipError_t ge = build_gamma_table(ctx->d_gamma, nullptr);
+      if (ge == hipSuccess) ge = hipDeviceSynchronize();
+      if (ge != hipSuccess) return hip_fail("ptamd_create: gamma table", ge);
+    }
+  }
   hipDeviceProp_t prop;
   PT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   ctx->n_cus = prop.multiProcessorCount;
@@ -533,6 +544,7 @@ void ptamd_destroy(ptamd_context* ctx)
   for (auto& s : ctx->scenes) free_scene(s);
   for (auto& c : ctx->cubemaps) (void)hipFree(c.faces);
   (void)hipFree(ctx->d_stats);
+  (void)hipFree(ctx->d_gamma);
   (void)hipFree(ctx->d_tickets);
   (void)hipFree(ctx->d_heads);
   for (auto& c : ctx->sample_scratch) (void)hipFree(c.buf);
@@ -746,6 +758,32 @@ int ptamd_device_error_count(ptamd_context* ctx, uint64_t* out)
   unsigned long long v = 0;
   PT_HIP(hipMemcpy(&v, ctx->d_stats + 15, sizeof v, hipMemcpyDeviceToHost));
   *out = v;
+  return PTAMD_OK;
+}
+
+int ptamd_gamma_table_selftest(ptamd_context* ctx, uint64_t* out_checked, uint64_t* out_mismatches)
+{
+  if (!ctx || !out_checked || !out_mismatches) { set_error("ptamd_gamma_table_selftest: null argument"); return PTAMD_ERR_ARG; }
+  *out_checked = 0; *out_mismatches = 0;
+  if (!ctx->d_gamma) return PTAMD_OK;   // no table in use
+  PT_HIP(hipSetDevice(ctx->device));
+  float limit = 0.0f;                   // T[256]: the table form is used below it
+  PT_HIP(hipMemcpy(&limit, ctx->d_gamma + 256, sizeof limit, hipMemcpyDeviceToHost));
+  uint32_t limit_bits;
+  std::memcpy(&limit_bits, &limit, 4);
+  // every positive value below the limit, plus the 2^20 patterns from the limit on (those take the pt_powf form: must agree
+  // trivially), plus the negative half's first 2^20 and the NaN patterns' first 2^20
+  PT_HIP(hipMemsetAsync(ctx->d_stats + 14, 0, sizeof(unsigned long long), nullptr));
+  const uint32_t ranges[3][2] = { { 0u, limit_bits + (1u << 20) }, { 0x80000000u, 1u << 20 }, { 0x7F800000u, 1u << 20 } };
+  for (const auto& r : ranges) {
+    hipError_t e = launch_gamma_selftest(ctx->d_gamma, r[0], r[1], ctx->d_stats + 14, nullptr);
+    if (e != hipSuccess) return hip_fail("ptamd_gamma_table_selftest", e);
+    *out_checked += r[1];
+  }
+  PT_HIP(hipDeviceSynchronize());
+  unsigned long long bad = 0;
+  PT_HIP(hipMemcpy(&bad, ctx->d_stats + 14, sizeof bad, hipMemcpyDeviceToHost));
+  *out_mismatches = bad;
   return PTAMD_OK;
 }
 

@@ -134,6 +134,7 @@ SIGNATURES = {
     "ptamd_raytrace_stats": (C.c_int, [C.c_void_p, C.POINTER(Launch), C.POINTER(TraceStats)]),
     "ptamd_scene_info_get": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(SceneInfo)]),
     "ptamd_device_error_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "ptamd_gamma_table_selftest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ptamd_trace_rays": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
                                    C.POINTER(C.c_int32)]),
     "ptamd_host_bvh_trace": (C.c_int, [C.POINTER(Face), C.c_uint32, C.POINTER(C.c_float), C.c_uint32,

@@ -153,6 +153,12 @@ class Context:
                                            len(rays), out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
+    def gamma_table_selftest(self):
+        """(values checked, mismatches) of the tonemap's gamma table against the pow sequence it replaces; synchronises."""
+        n, bad = C.c_uint64(), C.c_uint64()
+        N.check(self._lib.ptamd_gamma_table_selftest(self._h, C.byref(n), C.byref(bad)))
+        return n.value, bad.value
+
     def device_error_count(self) -> int:
         """Protocol time-outs of the split kernel since creation (0 unless there is a bug); synchronises."""
         v = C.c_uint64()

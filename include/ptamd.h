@@ -299,6 +299,13 @@ int ptamd_scene_info_get(ptamd_context* ctx, uint32_t scene_id, ptamd_scene_info
  * a non-zero count means frames rendered by PTAMD_KERNEL_BVH_SPLIT are incomplete). */
 int ptamd_device_error_count(ptamd_context* ctx, uint64_t* out);
 
+/* Test hook.  The resolve pass reads the byte the reference's gamma + store sequence (raytrace.cu:262-268: powf(c, 1/2.2),
+ * c * 255 through a truncating conversion) produces off a 256-step table built once per context with that very sequence
+ * (PTAMD_GAMMA_TABLE=0: no table).  This compares the table form with the sequence itself for every binary32 value the
+ * table form is used for (all positive values below the 256th step) plus samples of the values it hands back to the
+ * sequence, on the device: *out_mismatches must be 0. */
+int ptamd_gamma_table_selftest(ptamd_context* ctx, uint64_t* out_checked, uint64_t* out_mismatches);
+
 /* Nearest-hit query on explicit rays through the device traversal (tests: BVH vs brute
  * force equivalence).  kernel: PTAMD_KERNEL_BRUTE_FORCE, PTAMD_KERNEL_BVH (binary walk) or
  * PTAMD_KERNEL_BVH_RESTART (the four-wide stack walk).  rays: n * {dir.xyz, origin.xyz};

@@ -649,6 +649,18 @@ def test_scene_with_huge_coordinates(P, O, gpu_ctx):
         assert_same(acc, rgba, *ref, f"far scene/{kernel}")
 
 
+def test_gamma_table_matches_the_pow_sequence(P, gpu_ctx):
+    """The resolve pass reads the surface byte of a tonemapped channel off a 256-step table (pt_kernels.hip: gamma_byte) instead
+    of evaluating pt_powf per channel.  On the device, for EVERY positive binary32 value below the table's last step (about 2^30
+    of them) plus samples of the values it hands back to the pow sequence (large, negative, NaN): table form == sequence."""
+    checked, bad = gpu_ctx.gamma_table_selftest()
+    if os.environ.get("PTAMD_GAMMA_TABLE", "1") == "0":
+        assert checked == 0 and bad == 0
+        return
+    assert checked > 1_000_000_000, checked
+    assert bad == 0, f"{bad} of {checked} values differ"
+
+
 def test_one_texel_cubemaps(P, O, gpu_ctx):
     """1x1 cubemaps: six different texels (the face choice matters), six identical ones (the launcher's one-colour shortcut:
     env_lookup returns the colour without a lookup), identical rgb with different alpha (still one colour), and rgb that differs
