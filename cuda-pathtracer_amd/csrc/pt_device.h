@@ -268,6 +268,8 @@ struct KParams {
   uint32_t width, height, row_begin, row_end;
   uint32_t hash_seed;
   float frame_nb_f;   // (float)frame_nb
+  float frame_nb_inv; // 1 / frame_nb_f when frame_nb_f is a power of two (then x * frame_nb_inv is x / frame_nb_f for every x: the
+                      // same real number rounded once), else 0: the epilogue's three divisions become multiplies (4, 8, 16 spp)
   int32_t is_static;
   int32_t bounces;
   uint32_t post_id;

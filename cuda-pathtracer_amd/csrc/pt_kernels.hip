@@ -828,7 +828,7 @@ PT_DEV void path_finish(const KParams& p, const Path& st)
   t = t * (float)p.is_static;
   t = t + rad;
   tp[0] = t.x; tp[1] = t.y; tp[2] = t.z;
-  rad = t / p.frame_nb_f;
+  rad = p.frame_nb_inv != 0.0f ? t * p.frame_nb_inv : t / p.frame_nb_f;
   rad = exposure(rad);
   uint32_t px;
   if (p.gamma_table && p.post_id == 0u) {   // the byte read off the gamma table (two loads per channel) instead of three pt_powf
@@ -1885,7 +1885,7 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel(const KParams p)
     t = t + mk3(sp[0], sp[1], sp[2]);
   }
   tp[0] = t.x; tp[1] = t.y; tp[2] = t.z;
-  f3 rad = t / p.frame_nb_f; // (float)(frame_nb0 + count - 1)
+  f3 rad = p.frame_nb_inv != 0.0f ? t * p.frame_nb_inv : t / p.frame_nb_f; // (float)(frame_nb0 + count - 1); KParams::frame_nb_inv
   rad = exposure(rad);
   uint32_t px;
   if (p.gamma_table && p.post_id == 0u) {
@@ -1933,7 +1933,8 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel4(const KParams p)
   uint32_t px[4];
   const float g22 = 1.0f / 2.2f;
   for (int q = 0; q < 4; ++q) {
-    f3 rad = mk3(t[q * 3 + 0], t[q * 3 + 1], t[q * 3 + 2]) / p.frame_nb_f;
+    const f3 tq = mk3(t[q * 3 + 0], t[q * 3 + 1], t[q * 3 + 2]);
+    f3 rad = p.frame_nb_inv != 0.0f ? tq * p.frame_nb_inv : tq / p.frame_nb_f;   // KParams::frame_nb_inv
     rad = exposure(rad);
     if (use_table) {
       px[q] = gamma_byte(rad.x, s_gamma) | (gamma_byte(rad.y, s_gamma) << 8) | (gamma_byte(rad.z, s_gamma) << 16);

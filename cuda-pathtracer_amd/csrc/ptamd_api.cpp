@@ -93,6 +93,16 @@ namespace ptamd {
 namespace {
 
 constexpr size_t kLdsBudget = 64 * 1024;
+
+// 1 / c for a positive power of two c (KParams::frame_nb_inv), else 0
+float frame_nb_inverse(float c)
+{
+  uint32_t bits;
+  std::memcpy(&bits, &c, 4);
+  const uint32_t exponent = bits >> 23;   // sign bit included: negative values fail the range test
+  if ((bits & 0x007FFFFFu) != 0u || exponent < 1u || exponent > 253u) return 0.0f;
+  return 1.0f / c;
+}
 constexpr uint32_t kCompactMaxNodes = 896;   // 896 * 32 B = 28 KB of boxes below 0x8000 with 4 KB to spare for static LDS
 constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit)
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
@@ -216,6 +226,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   p.width = l->width; p.height = l->height; p.row_begin = l->row_begin; p.row_end = l->row_end;
   p.hash_seed = ptamd_wang_hash(l->frame_nb);
   p.frame_nb_f = (float)(int)l->frame_nb;
+  p.frame_nb_inv = frame_nb_inverse(p.frame_nb_f);
   p.is_static = l->moved ? 0 : 1;
   p.bounces = (int32_t)l->bounces;
   p.post_id = l->post_id;
@@ -372,6 +383,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     if (n_blocks > useful) n_blocks = useful;
     // seeds of frames frame_nb+1.. are hashed on the device; the tonemap uses the last frame number
     if (count > 1) p.frame_nb_f = (float)(int)(l->frame_nb + count - 1u);
+    p.frame_nb_inv = frame_nb_inverse(p.frame_nb_f);
     // the restart kernel parks every sample (also of a single frame: pt_resolve_kernel accumulates and tonemaps) and
     // keeps a 3 KiB pool of fresh paths per wave
     const bool parks = count > 1 || restart;
