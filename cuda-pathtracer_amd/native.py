@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libptamd.so")
@@ -156,6 +157,16 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64, and libptamd.so names
+    # the same sonames.  Loaded after torch, the library binds to the copies torch brought (one runtime, shared device state);
+    # loaded BEFORE torch it pulls in /opt/rocm's copies, torch then brings its own, and whichever initialises second finds
+    # "no ROCm-capable device" (seen on the GPU box: build() + smoke() in one interpreter).  So torch, when it is installed,
+    # is imported first.  Hosts without torch (C++, or Python with PTAMD_NO_TORCH_PRELOAD=1) are unaffected.
+    if "torch" not in sys.modules and os.environ.get("PTAMD_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP library has not been built. "

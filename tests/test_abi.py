@@ -166,3 +166,15 @@ def test_optional_gl_presenter_builds_and_refuses_to_run_without_a_context(P, tm
                    'int f(ptamd_host::Interop& i, ptamd_gl_presenter* g) { return i.blit(g, nullptr); }\n')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-c", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "cuda-pathtracer_amd", "host"), str(src), "-o", str(tmp_path / "with_gl.o")])
+
+
+def test_native_load_brings_torch_in_first():
+    """One HIP runtime per process: libptamd.so must bind to the libamdhip64 / libhsa-runtime64 PyTorch bundles, so native.load()
+    imports torch (when installed) before it dlopens the library — build() followed by smoke() in one interpreter found
+    "no ROCm-capable device" on the GPU box when the order was the other way round."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import cuda_pathtracer_amd as P; assert 'torch' not in sys.modules; "
+            "P.native.load(); assert 'torch' in sys.modules; print('ok')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
