@@ -425,15 +425,26 @@ def main():
         # (c) the other single-GPU configurations of BASELINE.json, a few steps each
         if is_headline and args.kernel == "restart":
             others = []
-            for name, scene_path, (w2, h2, s2, b2), ap, k in (
+            def load_textured_indoor():
+                return P.HostScene.load(args.scene, normalise_backslashes=True)
+
+            def load_crate_land():
+                return P.HostScene.load(os.path.join(ROOT, "assets", "crate_land.scene"))
+
+            for name, loader, (w2, h2, s2, b2), ap, k in (
                     ("configs[3]: atrium.obj (generated Sponza-class OBJ, 264 832 triangles, through the loader; walked from L2) "
-                     "1920x1080 4 spp 4 bounces", None, (1920, 1080, 4, 4), None, 6),
+                     "1920x1080 4 spp 4 bounces", lambda: P.HostScene.load(atrium_scene()), (1920, 1080, 4, 4), None, 6),
                     ("configs[4]: indoor.scene 3840x2160 16 spp 8 bounces aperture 0.113",
-                     args.scene, (3840, 2160, 16, 8), 0.113, 3)):
-                sc = P.HostScene.load(scene_path if scene_path is not None else atrium_scene())
+                     lambda: P.HostScene.load(args.scene), (3840, 2160, 16, 8), 0.113, 3),
+                    # the texture path (sampleTexture + normal maps, intersection.cuh:20-65,216-242): dependent 16 B / 12 B gathers
+                    ("textured indoor.scene: the maps indoor.mtl names (backslash paths normalised; 1024^2 parquet / concrete albedo + normal "
+                     "maps, wooden_planck, crack2: 66 MB of float texels) 1920x1080 4 spp 4 bounces", load_textured_indoor, (1920, 1080, 4, 4), None, 8),
+                    ("crate_land.scene: 1024^2 RGBA + normal maps, bilinear 1024^2 cubemap (field_with_house.jpg), aperture 0.113, "
+                     "1920x1080 4 spp 4 bounces", load_crate_land, (1920, 1080, 4, 4), None, 8)):
+                sc = loader()
                 if ap is not None:
                     sc.camera["aperture"] = ap
-                o = Workload(P, torch, dist, sc, P.cubemap_for_scene(sc), w2, h2, s2, b2, "restart", 2, True, True, local_rank)
+                o = Workload(P, torch, dist, sc, P.cubemap_for_scene(sc, asset_folder=os.path.join(ROOT, "assets")), w2, h2, s2, b2, "restart", 2, True, True, local_rank)
                 odt, o_ms = o.run(k, 1, args.settle_ms)
                 oi = o.info
                 o.close()

@@ -597,6 +597,41 @@ def test_crate_land_with_real_textures_and_cubemap(P, O, gpu_ctx):
         assert_same(acc, rgba, *ref, f"crate_land textured/{kernel}")
 
 
+@pytest.mark.parametrize("name", ["indoor_textured", "crate_land"])
+def test_textured_scenes_at_full_size(P, O, gpu_ctx, name):
+    """The dependent texel gathers of sampleTexture (intersection.cuh:20-65,216-242) at BASELINE.json's frame size:
+    indoor.obj with the textures its MTL names (parquet / concrete / wooden_planck albedo + normal maps: backslash
+    paths normalised) and crate_land.obj (1024^2 RGBA + normal maps, bilinear 1024^2 cubemap), 1920x1080,
+    4 spp, 4 bounces: default kernel (one batched launch and four consecutive launches) == one-thread-per-pixel kernel
+    on every pixel, plus the oracle on a crop of full-width rows."""
+    import torch
+    if name == "indoor_textured":
+        hs = P.HostScene.load(os.path.join(ASSETS, "indoor.scene"), normalise_backslashes=True)
+        assert hs.unloaded_textures == [] and len(hs.texels) > 16_000_000
+    else:
+        hs = P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"))
+        assert hs.unloaded_textures == []
+    cube = P.cubemap_for_scene(hs, asset_folder=ASSETS)
+    ids = (gpu_ctx.upload_scene(hs), gpu_ctx.upload_cubemap(cube))
+    W, H, spp, B = 1920, 1080, 4, 4
+    acc, rgba = gpu_render(P, gpu_ctx, hs, cube, W, H, spp, B, P.KERNEL_AUTO, ids=ids)
+    t_acc, t_rgba = gpu_render(P, gpu_ctx, hs, cube, W, H, spp, B, P.KERNEL_BVH, ids=ids)
+    assert_same(acc, rgba, t_acc, t_rgba, f"{name} 1080p default kernel vs tile kernel")
+    if batched_ok():
+        fr = P.FrameRenderer(gpu_ctx, ids[0], ids[1], hs.camera_struct(), W, H)
+        fr.render(spp=spp, bounces=B, batched=True)
+        torch.cuda.synchronize()
+        assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), acc, rgba, f"{name} 1080p batched")
+    rows = (600, 604)
+    buf = np.zeros((H, W, 3), np.float32)
+    ref_acc, ref_rgba = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), W, H,
+                                 spp=spp, bounces=B, rows=rows, accum=buf)
+    st = O.last_stats()
+    assert st["mesh_hits"] > 1000 and st["nmap_hits"] > 100
+    np.testing.assert_array_equal(rgba[rows[0]:rows[1]], ref_rgba[rows[0]:rows[1]])
+    np.testing.assert_array_equal(acc[H - rows[1]:H - rows[0]].view(np.uint32), ref_acc[H - rows[1]:H - rows[0]].view(np.uint32))
+
+
 def test_random_scenes_fuzz(P, O, gpu_ctx):
     """Seeded random scenes (triangle soups with textures, normal maps, refractive materials, 0-4 lights, random camera
     lens, ragged frame sizes, 1-7 bounces, every post-process) through the default kernel and the tile kernel."""
