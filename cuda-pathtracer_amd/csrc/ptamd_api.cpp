@@ -73,8 +73,30 @@ struct ptamd_context {
   struct Occupancy { size_t lds = ~(size_t)0; int blocks_per_cu = -1; } occupancy[4];
   // parked samples of batched launches, one scratch per stream: launches on one stream are ordered, launches on
   // different streams of one context (frames in flight, ptamd_launch.machine_share) must not share a buffer
-  struct SampleScratch { void* stream = nullptr; float* buf = nullptr; size_t bytes = 0; };
+  // Three slabs per stream.  [0], [1] are used in turn by launches whose megakernel runs on an internal stream (below), so
+  // that the megakernel of launch N+1 can write its samples while the resolve pass of launch N still reads its own; [2]
+  // belongs to launches that stay on the caller's stream from start to end (captured into a graph, instrumented, or part
+  // of the caller's own pipeline): stream order alone protects it, also against replays of a captured launch.
+  struct SampleScratch {
+    void* stream = nullptr;
+    float* buf[3] = { nullptr, nullptr, nullptr };
+    size_t bytes[3] = { 0, 0, 0 };
+    hipEvent_t mega_done[2] = { nullptr, nullptr };   // megakernel of the last launch that used slab i has finished
+    hipEvent_t resolved[2] = { nullptr, nullptr };    // resolve pass of the last launch that used slab i has finished
+    bool resolved_valid[2] = { false, false };
+    uint32_t flip = 0;
+  };
   std::vector<SampleScratch> sample_scratch;
+  // Consecutive launches on ONE caller stream overlap: the megakernel of a launch (which reads scene tables and writes only
+  // the context's scratch) runs on one of two internal streams, its resolve pass (the only part that touches the caller's
+  // accumulator and surface) on the caller's stream behind an event.  The tail of launch N — waves finishing the tiles
+  // they hold at falling occupancy once the tickets are gone — is then filled by the first workgroups of launch N+1, for
+  // a host that simply calls raytrace() again without synchronising (gpu_processor.cpp:365-386 does not).
+  hipStream_t internal[2] = { nullptr, nullptr };
+  bool overlap = true;                    // PTAMD_OVERLAP=0 (tuning): everything on the caller's stream
+  bool pool_share = true;                 // PTAMD_POOL_SHARE=0 (tuning): waves take fresh paths from their own pool only
+  unsigned long long* d_timeline = nullptr;   // ptamd_set_timeline: 4 time stamps per wave of the restart kernel
+  uint32_t timeline_waves = 0;
   uint32_t default_kernel = PTAMD_KERNEL_BVH_RESTART; // what PTAMD_KERNEL_AUTO means
   bool default_kernel_is_builtin = true;              // false once PTAMD_DEFAULT_KERNEL pinned it
   uint32_t refill_min = 0; // 0 = choose per launch (see do_launch); PTAMD_REFILL_MIN pins it
@@ -145,6 +167,16 @@ void free_scene(DeviceScene& s)
   void* ptrs[] = { s.nodes, s.nodes4, s.tris_bvh, s.tris_brute, s.shade, s.materials, s.lights, s.textures, s.texels };
   for (void* q : ptrs) (void)hipFree(q);
   s = DeviceScene();
+}
+
+void free_scratch(ptamd_context::SampleScratch& c)
+{
+  for (int i = 0; i < 3; ++i) (void)hipFree(c.buf[i]);
+  for (int i = 0; i < 2; ++i) {
+    if (c.mega_done[i]) (void)hipEventDestroy(c.mega_done[i]);
+    if (c.resolved[i]) (void)hipEventDestroy(c.resolved[i]);
+  }
+  c = ptamd_context::SampleScratch();
 }
 
 inline f3 hf3(ptamd_float3 v) { f3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
@@ -243,27 +275,42 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   uint32_t which = l->kernel == PTAMD_KERNEL_AUTO ? ctx->default_kernel : l->kernel;
   // Box margins cover the slab test's rounding, (|origin| + |plane|) * 2^-22, for origins inside the scene's extent
   // (bvh_builder.cpp).  A camera so far outside it that this bound exceeds the margin (e.g. 1e5 units from a
-  // unit-sized scene) would need wider boxes: such launches run the exhaustive face loop instead — the reference
-  // algorithm, exact for any origin.
+  // unit-sized scene) would need wider boxes: such launches test every face instead — the reference algorithm, exact
+  // for any origin — inside the restart kernel (KParams::brute_walk: all its launch shapes keep working, interleaved
+  // bands and batched frames included) or, for the other kernels, through the exhaustive tile kernel.
   const float cam_far = std::fmax(std::fabs(cam.position.x), std::fmax(std::fabs(cam.position.y), std::fabs(cam.position.z))) +
                         std::fabs(cam.aperture);
-  const bool far_origin = !((cam_far + s.extent) * (1.0f / 4194304.0f) <= s.margin_floor);   // also true for NaN
-  if (far_origin && s.n_faces != 0) which = PTAMD_KERNEL_BRUTE_FORCE;
+  const bool far_origin = !((cam_far + s.extent) * (1.0f / 4194304.0f) <= s.margin_floor) && s.n_faces != 0;   // also true for NaN
+  if (far_origin) {
+    if (which == PTAMD_KERNEL_BVH_RESTART) p.brute_walk = 1u;
+    else which = PTAMD_KERNEL_BRUTE_FORCE;
+  }
+  // only the restart kernel maps its tiles to the rows of interleaved bands; every other kernel would render the whole
+  // frame into the band-local buffers (PTAMD_DEFAULT_KERNEL behind PTAMD_KERNEL_AUTO can ask for one)
+  if (l->interleave_ranks > 1u && which != PTAMD_KERNEL_BVH_RESTART) {
+    set_error("ptamd_raytrace: interleaved bands need the restart kernel (PTAMD_KERNEL_AUTO resolves to another one here)");
+    return PTAMD_ERR_ARG;
+  }
   const int kind = which == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2;
   const size_t lds = kind == 1 ? s.info.lds_bytes_brute : s.info.lds_bytes_bvh;
   // the LDS copy of a BVH addresses its boxes with 15 bits (pt_kernels.hip: stage_scene): 32 bytes per node, nodes first
   const bool resident = lds <= kLdsBudget && (kind == 1 || s.n_nodes <= kCompactMaxNodes);
-  // PTAMD_KERNEL_AUTO, one frame per launch (the reference's interactive loop, ptamd_raytrace) on an LDS-resident scene:
-  // the persistent kernel writes the surface itself, the restart kernel would add its resolve pass to every launch
-  // (1080p, one launch per spp, one at a time: 6.03 vs 5.89 Gsamples/s).  A caller that keeps several such launches in
-  // flight (machine_share > 1) gets the restart kernel (two in flight: 7.92 vs 6.97), as do batched frames, big scenes
-  // and interleaved bands.
-  if (l->kernel == PTAMD_KERNEL_AUTO && which == PTAMD_KERNEL_BVH_RESTART && ctx->default_kernel_is_builtin && l->frame_count <= 1 &&
-      resident && l->interleave_ranks <= 1 && l->machine_share <= 1)
-    which = PTAMD_KERNEL_BVH_PERSISTENT;
   hipStream_t stream = static_cast<hipStream_t>(l->stream);
+  // Consecutive launches of the restart kernel on one stream overlap (ptamd_context::internal) unless the caller runs its
+  // own pipeline (machine_share > 1: several streams, each launch sized to its share), captures a graph, or wants counters
+  bool overlap = ctx->overlap && which == PTAMD_KERNEL_BVH_RESTART && l->machine_share <= 1u && !stats;
+  if (overlap && stream != nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) overlap = false;
+  }
+  // PTAMD_KERNEL_AUTO, one frame per launch (the reference's interactive loop, ptamd_raytrace) on an LDS-resident scene,
+  // when launches cannot overlap: the persistent kernel writes the surface itself, the restart kernel would add its
+  // resolve pass to every launch (1080p, one launch per spp, one at a time: 6.03 vs 5.89 Gsamples/s).
+  if (l->kernel == PTAMD_KERNEL_AUTO && which == PTAMD_KERNEL_BVH_RESTART && ctx->default_kernel_is_builtin && l->frame_count <= 1 &&
+      resident && l->interleave_ranks <= 1 && l->machine_share <= 1 && !overlap && !p.brute_walk)
+    which = PTAMD_KERNEL_BVH_PERSISTENT;
   hipError_t e;
-  if (far_origin && s.n_faces != 0 && l->frame_count > 1) {
+  if (far_origin && !p.brute_walk && l->frame_count > 1) {
     // batched frames == consecutive launches by contract: issue them that way
     for (uint32_t k = 0; k < l->frame_count; ++k) {
       ptamd_launch one = *l;
@@ -333,8 +380,8 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       const uint32_t share = 160u * 1024u / restart_wide_blocks_per_cu() - 256u;   // LDS bytes of one resident workgroup
       // the top of the tree (breadth-first numbering: nodes 0..340 are its first five levels when full) goes to LDS too:
       // 512 nodes = 64 KB of the one workgroup's 160 KB, then 7 stack entries per lane
-      // ... and the waves' pools of fresh paths (2 304 bytes each), behind the stacks
-      const uint32_t pools = ctx->pool_in_lds ? waves * 2304u : 0u;
+      // ... and the waves' pools of fresh paths (PT_POOL_LDS_BYTES each), behind the stacks
+      const uint32_t pools = waves * (ctx->pool_in_lds ? PT_POOL_LDS_BYTES : PT_POOL_HDR_BYTES);   // (global-slab entries: only the header)
       uint32_t treelet = ctx->treelet_nodes < s.n_nodes4 ? ctx->treelet_nodes : s.n_nodes4;
       if (treelet * 128u + waves * 512u * 4u + pools > share) treelet = (share - pools - waves * 512u * 4u) / 128u;   // keep >= 4 stack entries
       uint32_t fit = (share - pools - treelet * 128u) / (waves * 512u);
@@ -343,19 +390,21 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       p.stack_lds_entries = need < fit ? need : fit;
       p.stack_spill_entries = need - p.stack_lds_entries;
       launch_lds = (size_t)treelet * 128u + (size_t)p.stack_lds_entries * waves * 512u;
-      if (pools) { p.pool_lds_offset = (uint32_t)launch_lds; if (!p.pool_lds_offset) p.pool_lds_offset = 16u; launch_lds = p.pool_lds_offset + pools; }
+      p.pool_lds_offset = (uint32_t)launch_lds;
+      p.pool_in_lds = ctx->pool_in_lds ? 1u : 0u;
+      launch_lds = p.pool_lds_offset + pools;
     }
     if (restart && resident) {
-      // pools of fresh paths in LDS when two workgroups with their scene copies leave room for them (2 304 bytes per
-      // wave); else in a global slab (3 KiB per wave, L2-resident)
+      // pools of fresh paths in LDS when two workgroups with their scene copies leave room for them (PT_POOL_LDS_BYTES
+      // per wave); else in a global slab (3 KiB per wave, L2-resident)
       const uint32_t waves = restart_threads(true) / 64u;
-      const size_t with_pools = ((lds + 15u) & ~(size_t)15u) + (size_t)waves * 2304u;
+      const size_t with_pools = ((lds + 15u) & ~(size_t)15u) + (size_t)waves * PT_POOL_LDS_BYTES;
       const size_t blocks_wanted = (24u + waves - 1u) / waves;             // 24 waves per CU
-      if (ctx->pool_in_lds && with_pools * blocks_wanted + 1024u <= 160u * 1024u) {
-        p.pool_lds_offset = (uint32_t)((lds + 15u) & ~(size_t)15u);
-        if (p.pool_lds_offset == 0) p.pool_lds_offset = 16u;               // (an empty scene: keep the flag non-zero)
-        launch_lds = p.pool_lds_offset + (size_t)waves * 2304u;
-      }
+      p.pool_lds_offset = (uint32_t)((lds + 15u) & ~(size_t)15u);
+      p.pool_in_lds = (ctx->pool_in_lds && with_pools * blocks_wanted + 1024u <= 160u * 1024u) ? 1u : 0u;
+      // (the header — read cursors, reader counts, tile descriptors: 32 bytes per wave — always fits: a resident scene takes
+      // at most 64 KB of a workgroup's 80)
+      launch_lds = p.pool_lds_offset + (size_t)waves * (p.pool_in_lds ? PT_POOL_LDS_BYTES : PT_POOL_HDR_BYTES);
     }
     ptamd_context::Occupancy& occ = ctx->occupancy[split ? 2 : (restart ? 3 : 0)];
     const size_t occ_key = resident ? (restart ? launch_lds : lds) : (restart ? launch_lds + 1u : 0);
@@ -387,36 +436,49 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     // the restart kernel parks every sample (also of a single frame: pt_resolve_kernel accumulates and tonemaps) and
     // keeps a 3 KiB pool of fresh paths per wave
     const bool parks = count > 1 || restart;
+    ptamd_context::SampleScratch* sc = nullptr;
+    uint32_t scratch_slab = 0;
     if (parks) {
       const size_t sample_bytes = ((size_t)count * rows * l->width * 3u * sizeof(float) + 255u) & ~(size_t)255u;
-      const size_t pool_bytes = (restart && !p.pool_lds_offset) ? (size_t)n_blocks * waves_per_block * 192u * sizeof(float4) : 0u;
+      const size_t pool_bytes = (restart && !p.pool_in_lds) ? (size_t)n_blocks * waves_per_block * 192u * sizeof(float4) : 0u;
       const size_t spill_bytes = (size_t)n_blocks * waves_per_block * p.stack_spill_entries * 512u;
       const size_t need = sample_bytes + pool_bytes + spill_bytes + 16u;
-      ptamd_context::SampleScratch* sc = nullptr;
+      uint32_t& slab = scratch_slab;
       for (auto& c : ctx->sample_scratch) if (c.stream == l->stream) sc = &c;
       if (!sc) {
         if (ctx->sample_scratch.size() >= kMaxScratchStreams) {
           // a host cycling through short-lived streams: drop every scratch once nothing can be using them
           PT_HIP(hipDeviceSynchronize());
-          for (auto& c : ctx->sample_scratch) (void)hipFree(c.buf);
+          for (auto& c : ctx->sample_scratch) free_scratch(c);
           ctx->sample_scratch.clear();
         }
         ctx->sample_scratch.emplace_back();
         sc = &ctx->sample_scratch.back();
         sc->stream = l->stream;
       }
-      if (need > sc->bytes) {
-        // only launches of this stream ever used the old buffer (the default stream also waits for the others)
-        PT_HIP(hipStreamSynchronize(stream));
-        (void)hipFree(sc->buf);
-        sc->buf = nullptr; sc->bytes = 0;
-        PT_HIP(hipMalloc(reinterpret_cast<void**>(&sc->buf), need));
-        sc->bytes = need;
+      slab = overlap ? (sc->flip++ & 1u) : 2u;
+      if (overlap && !ctx->internal[slab]) PT_HIP(hipStreamCreateWithFlags(&ctx->internal[slab], hipStreamNonBlocking));
+      for (int i = 0; i < 2 && overlap; ++i) {
+        if (!sc->mega_done[i]) PT_HIP(hipEventCreateWithFlags(&sc->mega_done[i], hipEventDisableTiming));
+        if (!sc->resolved[i]) PT_HIP(hipEventCreateWithFlags(&sc->resolved[i], hipEventDisableTiming));
       }
-      p.samples_out = sc->buf;
-      p.pool = reinterpret_cast<float4*>(reinterpret_cast<char*>(sc->buf) + sample_bytes);
-      p.stack_spill = reinterpret_cast<uint2*>(reinterpret_cast<char*>(sc->buf) + sample_bytes + pool_bytes);
+      // the slab of this launch, and with it the in-stream slab: a launch captured into a graph later must find its scratch
+      // sized already (allocating would break the capture), whichever way the launches before it went
+      for (uint32_t i : { slab, 2u }) {
+        if (need <= sc->bytes[i]) continue;
+        // launches of this stream (their megakernels possibly on the internal streams) are the only users of the old buffer
+        PT_HIP(hipStreamSynchronize(stream));
+        for (hipStream_t is : ctx->internal) if (is) PT_HIP(hipStreamSynchronize(is));
+        (void)hipFree(sc->buf[i]);
+        sc->buf[i] = nullptr; sc->bytes[i] = 0;
+        PT_HIP(hipMalloc(reinterpret_cast<void**>(&sc->buf[i]), need));
+        sc->bytes[i] = need;
+      }
+      p.samples_out = sc->buf[slab];
+      p.pool = reinterpret_cast<float4*>(reinterpret_cast<char*>(sc->buf[slab]) + sample_bytes);
+      p.stack_spill = reinterpret_cast<uint2*>(reinterpret_cast<char*>(sc->buf[slab]) + sample_bytes + pool_bytes);
     }
+    p.pool_share = ctx->pool_share ? 1u : 0u;
     p.round_min = ctx->round_min;
     p.round_div = ctx->round_div;
     p.walk_min = ctx->walk_min;
@@ -427,19 +489,36 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     p.tile_counter = ctx->d_tickets + slot;
     p.n_static = n_blocks * waves_per_block;
     if (split) PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)p.n_static, 1, stream));
+    hipStream_t mega_stream = stream;
+    if (overlap) {
+      // the megakernel touches nothing of the caller's: it may start before earlier work on the caller's stream has finished,
+      // as soon as the slab's previous reader (the resolve pass two launches back) is done
+      mega_stream = ctx->internal[scratch_slab];
+      if (sc->resolved_valid[scratch_slab]) PT_HIP(hipStreamWaitEvent(mega_stream, sc->resolved[scratch_slab], 0));
+    }
     if (!split) {
       p.tile_heads = ctx->d_heads + (size_t)slot * 8u * PT_HEAD_STRIDE;
       // the whole ring is zeroed at creation and a launch that parks its samples has its resolve pass zero its heads
       // again (pt_resolve_kernel); only slots whose last user did not get that far are cleared here
-      if (!ctx->heads_clean[slot]) PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_heads), 0, 8u * PT_HEAD_STRIDE, stream));
+      if (!ctx->heads_clean[slot]) PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_heads), 0, 8u * PT_HEAD_STRIDE, mega_stream));
       ctx->heads_clean[slot] = false;
     }
+    if (restart && ctx->d_timeline && n_blocks * waves_per_block <= ctx->timeline_waves) p.timeline = ctx->d_timeline;
     if (split) { p.tiles_per_ticket = 1; e = launch_megakernel_split(p, resident, lds, stats, n_blocks, stream); }
-    else if (restart) e = launch_megakernel_restart(p, resident, launch_lds, stats, n_blocks, stream);
+    else if (restart) e = launch_megakernel_restart(p, resident, launch_lds, stats, n_blocks, mega_stream);
     else e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
+    if (e == hipSuccess && overlap) {
+      PT_HIP(hipEventRecord(sc->mega_done[scratch_slab], mega_stream));
+      PT_HIP(hipStreamWaitEvent(stream, sc->mega_done[scratch_slab], 0));
+    }
     if (e == hipSuccess && parks) {
       e = launch_resolve(p, stream);
       if (e == hipSuccess && !split) ctx->heads_clean[slot] = true;
+      if (e == hipSuccess && overlap) {
+        // whoever writes this slab next (a megakernel on an internal stream) waits for this pass
+        PT_HIP(hipEventRecord(sc->resolved[scratch_slab], stream));
+        sc->resolved_valid[scratch_slab] = true;
+      }
     }
   } else {
     e = launch_megakernel(p, kind, resident, lds, stats, stream);
@@ -533,6 +612,8 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   }
   if (const char* e = std::getenv("PTAMD_SHORT_RCP")) ctx->short_rcp = std::atoi(e) != 0; // tuning knob
   if (const char* e = std::getenv("PTAMD_POOL_LDS")) ctx->pool_in_lds = std::atoi(e) != 0; // tuning knob
+  if (const char* e = std::getenv("PTAMD_OVERLAP")) ctx->overlap = std::atoi(e) != 0; // tuning knob
+  if (const char* e = std::getenv("PTAMD_POOL_SHARE")) ctx->pool_share = std::atoi(e) != 0; // tuning knob
   if (const char* e = std::getenv("PTAMD_TREELET")) { // tuning knob
     int v = std::atoi(e);
     ctx->treelet_nodes = (uint32_t)(v < 0 ? 0 : (v > 1024 ? 1024 : v));
@@ -559,7 +640,10 @@ void ptamd_destroy(ptamd_context* ctx)
   (void)hipFree(ctx->d_gamma);
   (void)hipFree(ctx->d_tickets);
   (void)hipFree(ctx->d_heads);
-  for (auto& c : ctx->sample_scratch) (void)hipFree(c.buf);
+  (void)hipDeviceSynchronize();   // megakernels on the internal streams included
+  for (auto& c : ctx->sample_scratch) free_scratch(c);
+  for (hipStream_t is : ctx->internal) if (is) (void)hipStreamDestroy(is);
+  (void)hipFree(ctx->d_timeline);
   delete ctx;
 }
 
@@ -796,6 +880,35 @@ int ptamd_gamma_table_selftest(ptamd_context* ctx, uint64_t* out_checked, uint64
   unsigned long long bad = 0;
   PT_HIP(hipMemcpy(&bad, ctx->d_stats + 14, sizeof bad, hipMemcpyDeviceToHost));
   *out_mismatches = bad;
+  return PTAMD_OK;
+}
+
+int ptamd_set_timeline(ptamd_context* ctx, uint32_t max_waves)
+{
+  if (!ctx) { set_error("ptamd_set_timeline: null context"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  PT_HIP(hipDeviceSynchronize());
+  (void)hipFree(ctx->d_timeline);
+  ctx->d_timeline = nullptr; ctx->timeline_waves = 0;
+  if (max_waves == 0) return PTAMD_OK;
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_timeline), (size_t)max_waves * 4u * sizeof(unsigned long long)));
+  PT_HIP(hipMemset(ctx->d_timeline, 0, (size_t)max_waves * 4u * sizeof(unsigned long long)));
+  ctx->timeline_waves = max_waves;
+  return PTAMD_OK;
+}
+
+int ptamd_read_timeline(ptamd_context* ctx, uint64_t* out, uint32_t n_waves, uint32_t* clock_khz)
+{
+  if (!ctx || !out || n_waves > ctx->timeline_waves) { set_error("ptamd_read_timeline: bad argument"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  PT_HIP(hipDeviceSynchronize());
+  PT_HIP(hipMemcpy(out, ctx->d_timeline, (size_t)n_waves * 4u * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  PT_HIP(hipMemset(ctx->d_timeline, 0, (size_t)ctx->timeline_waves * 4u * sizeof(unsigned long long)));
+  if (clock_khz) {
+    int khz = 0;
+    PT_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    *clock_khz = (uint32_t)khz;
+  }
   return PTAMD_OK;
 }
 

@@ -153,6 +153,18 @@ class Context:
                                            len(rays), out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
+    def set_timeline(self, max_waves: int) -> None:
+        """Per-wave time stamps of the default kernel's launches (ptamd_set_timeline); 0 = off."""
+        N.check(self._lib.ptamd_set_timeline(self._h, max_waves))
+
+    def read_timeline(self, n_waves: int):
+        """uint64[n_waves, 4] = (entry, scene staged, no ticket left, exit) in device-clock ticks, and the clock in kHz;
+        synchronises and clears the buffer.  Rows of waves the last launches did not have are 0."""
+        out = np.zeros((n_waves, 4), dtype=np.uint64)
+        khz = C.c_uint32()
+        N.check(self._lib.ptamd_read_timeline(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), n_waves, C.byref(khz)))
+        return out, khz.value
+
     def gamma_table_selftest(self):
         """(values checked, mismatches) of the tonemap's gamma table against the pow sequence it replaces; synchronises."""
         n, bad = C.c_uint64(), C.c_uint64()

@@ -287,6 +287,15 @@ typedef struct {
  * returns exact traversal counts (synchronous; outputs are written as usual). */
 int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_trace_stats* out);
 
+/* Where a launch's time goes (measurement hook of the default kernel; profiles/r03_tail_*).  After ptamd_set_timeline(ctx, n)
+ * every launch of PTAMD_KERNEL_BVH_RESTART with at most n waves in its grid records four device time stamps per wave
+ * (hipDeviceAttributeWallClockRate ticks): kernel entry, scene staged, the moment the wave found no tile ticket left, exit.
+ * ptamd_read_timeline synchronises, copies 4 * n_waves words ([wave][stamp]; waves of workgroup b are b * waves_per_group ..;
+ * words of waves a launch did not have stay 0) and clears the buffer.  n = 0 switches the recording off.  Costs two scalar
+ * loads per wave when off. */
+int ptamd_set_timeline(ptamd_context* ctx, uint32_t max_waves);
+int ptamd_read_timeline(ptamd_context* ctx, uint64_t* out, uint32_t n_waves, uint32_t* clock_khz);
+
 typedef struct {
   uint32_t n_faces, n_lights, n_nodes, n_leaves, max_leaf_size, depth;
   uint32_t node_bytes, tri_bytes, lds_bytes_bvh, lds_bytes_brute;

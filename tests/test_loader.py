@@ -305,5 +305,9 @@ def test_ldr_to_float_and_real_assets(P):
     # indoor.mtl names its textures with backslashes: not found on Linux (reference behaviour) unless normalised
     ind = P.HostScene.load(os.path.join(ASSETS, "indoor.scene"), normalise_backslashes=True)
     got = {(int(t["w"]), int(t["h"]), int(t["nb_chan"])) for t in ind.textures}
-    assert (512, 512, 4) in got and (512, 512, 3) in got        # wooden_planck/albedo_2.jpg, crack2.jpg (the two shipped here)
-    assert "textures\\parquet\\albedo_1.jpg" in ind.unloaded_textures
+    assert (512, 512, 4) in got and (512, 512, 3) in got        # wooden_planck/albedo_2.jpg, crack2.jpg
+    assert (1024, 1024, 4) in got and (1024, 1024, 3) in got    # parquet / concrete albedo + normal maps
+    assert ind.unloaded_textures == []
+    # the reference's own behaviour on Linux: none of them is found, every material degrades to its 1x1 constant
+    ref = P.HostScene.load(os.path.join(ASSETS, "indoor.scene"))
+    assert "textures\\parquet\\albedo_1.jpg" in ref.unloaded_textures and all(int(t["w"]) == 1 for t in ref.textures)
