@@ -17,8 +17,12 @@ The headline (`value`) issues the spp frames of a step as ONE batched launch (pt
 accumulator and surface as spp consecutive launches, bit for bit) and keeps two (one GPU) or four (several GPUs) steps
 in flight on separate HIP streams, each launch sized to its share of the GPU, so that a step's ramp, tail, resolve pass
 and all-gather overlap the bulk of the next one.  Next to it, at N = 1, the line reports
-  value_unpipelined  the same batched launch, one at a time (frames_in_flight = 1): `ms_per_frame` is its latency;
-  value_sequential   SURVEY §8-d's literal definition: spp launches per frame, one after the other, one frame at a time;
+  value_unpipelined  the same batched launch issued back to back on ONE stream by a host that does not wait between frames
+                     (frames_in_flight = 1; the library itself overlaps consecutive launches of a stream: DESIGN.md);
+  value_sequential   SURVEY §8-d's literal definition: spp launches per frame, one after the other on one stream — the
+                     reference's own call pattern (gpu_processor.cpp:365-386 issues a frame and does not wait for it);
+  value_host_sync    the batched launch with a host synchronisation after every frame: nothing can overlap, `ms_per_frame`
+                     is this latency; value_sequential_host_sync: the same for one launch per spp;
   other_configs      BASELINE.json configs[3] and configs[4], a few steps each.
 
 `roofline`: the megakernel is VALU-issue / lane-divergence bound (no HBM or MFMA roof is within two orders of
@@ -248,7 +252,7 @@ class Workload:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def run(self, steps, warmup, settle_ms=0.0):
+    def run(self, steps, warmup, settle_ms=0.0, sync_each=False):
         """`settle_ms` of untimed rendering (no collective: ranks need not agree on the count), W untimed steps, then
         exactly K timed steps between barriers.  Returns (wall seconds, mean ms between the HIP events that bracket one
         step's launches on its stream).  The settle phase exists because an idle MI355X needs ~30 ms of load to reach its
@@ -268,6 +272,8 @@ class Workload:
         t0 = time.perf_counter()
         for i in range(steps):
             self.step(evs[i])
+            if sync_each:   # a host that waits for every frame before it issues the next one
+                torch.cuda.synchronize()
         self.barrier()
         dt = time.perf_counter() - t0
         if self.world > 1:
@@ -404,24 +410,24 @@ def main():
     is_headline = (W, H, spp, B, args.tessellate, args.aperture, args.atrium, proxy) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None, False, False)
     if world == 1 and not args.no_extra and not force_gather and not proxy:
         k2 = max(4, args.steps // 2)
-        # (a) the same batched launch, one at a time: a frame's latency and the unpipelined rate
-        if n_slots > 1:
-            solo = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, 1, False, not args.sequential, local_rank)
-            sdt, s_ms = solo.run(k2, 2, args.settle_ms)
-            solo.close()
-            extra["value_unpipelined"] = round(W * H * spp * k2 / sdt / 1e6, 3)
-            extra["ms_per_frame"] = round(s_ms, 4)
-        else:
-            extra["value_unpipelined"] = round(value, 3)
-            extra["ms_per_frame"] = round(step_ms, 4)
-        # (b) SURVEY §8-d's literal metric: spp launches per frame, one frame at a time
+        # (a) the same batched launch on one stream: issued back to back, and with the host waiting for every frame (latency)
+        solo = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, 1, False, not args.sequential, local_rank)
+        sdt, s_ms = solo.run(k2, 2, args.settle_ms)
+        extra["value_unpipelined"] = round(W * H * spp * k2 / sdt / 1e6, 3)
+        hdt, h_ms = solo.run(k2, 2, 0.0, sync_each=True)
+        solo.close()
+        extra["value_host_sync"] = round(W * H * spp * k2 / hdt / 1e6, 3)
+        extra["ms_per_frame"] = round(h_ms, 4)
+        # (b) SURVEY §8-d's literal metric: spp launches per frame on one stream
         if not args.sequential:
-            # (PTAMD_KERNEL_AUTO: what a host that calls raytrace() once per spp gets — the persistent kernel on this scene)
+            # (PTAMD_KERNEL_AUTO: what a host that calls raytrace() once per spp gets)
             seq = Workload(P, torch, dist, hs, cube, W, H, spp, B, "auto" if args.kernel == "restart" else args.kernel, 1, False, False, local_rank)
             qdt, q_ms = seq.run(k2, 2, args.settle_ms)
-            seq.close()
             extra["value_sequential"] = round(W * H * spp * k2 / qdt / 1e6, 3)
             extra["ms_per_frame_sequential"] = round(q_ms, 4)
+            qdt, q_ms = seq.run(k2, 2, 0.0, sync_each=True)
+            seq.close()
+            extra["value_sequential_host_sync"] = round(W * H * spp * k2 / qdt / 1e6, 3)
         # (c) the other single-GPU configurations of BASELINE.json, a few steps each
         if is_headline and args.kernel == "restart":
             others = []

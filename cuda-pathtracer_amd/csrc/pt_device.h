@@ -297,9 +297,7 @@ struct KParams {
   float* samples_out;
   // restart kernel: per-wave pools of fresh paths (192 float4 per wave) and the straggler threshold of a round
   float4* pool;
-  uint32_t pool_lds_offset;   // the workgroup's pool area starts this many bytes into the dynamic LDS: entries (when pool_in_lds), then the header
-  uint32_t pool_in_lds;       // != 0: the pools' entries live in LDS (PT_POOL_LDS_BYTES per wave in all); 0: in the global slab `pool`, LDS holds
-                              // only the header (PT_POOL_HDR_BYTES per wave)
+  uint32_t pool_lds_offset;   // != 0: the pools live in LDS this many bytes behind the start of the dynamic LDS (2 304 bytes per wave)
   uint32_t round_min, round_div;
   uint32_t walk_min;   // a box phase ends once fewer lanes than this are still walking (1: when none is)
   uint32_t small_det;  // != 0: the scene's coordinates are <= 1e8, so Moller-Trumbore determinants stay below 2^125
@@ -321,14 +319,11 @@ struct KParams {
   uint32_t treelet_nodes;   // the first nodes of nodes4 (top of the tree) are staged in LDS in front of the stacks
   uint2* stack_spill;
   uint32_t walk_min4;
-  uint32_t pool_share;            // restart kernel: 0 = a wave only ever takes paths from its own pool (A/B knob PTAMD_POOL_SHARE)
-  uint32_t brute_walk;            // restart kernel: test every triangle record instead of walking the tree (far-origin launches)
-  unsigned long long* timeline;   // restart kernel: 4 time stamps per wave (ptamd_set_timeline) or nullptr
+  uint32_t brute_walk;            // restart kernel: the launch wants the instantiation that tests every triangle record instead of walking the tree (far origin)
+  unsigned long long* timeline;   // restart kernel: != nullptr selects the instantiation that records 4 time stamps per wave (ptamd_set_timeline)
 };
-// LDS bytes of one wave's pool of fresh paths (restart kernel): 64 entries x 9 dwords + cursor, reader count and the tile's
-// four descriptor words, rounded up to 16 bytes
-#define PT_POOL_LDS_BYTES 2336u
-#define PT_POOL_HDR_BYTES 32u
+// LDS bytes of one wave's pool of fresh paths (restart kernel: 64 entries x 9 dwords)
+#define PT_POOL_LDS_BYTES 2304u
 
 // one intersect() result carried through radiance()
 struct Hit {

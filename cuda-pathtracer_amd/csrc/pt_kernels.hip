@@ -1324,59 +1324,44 @@ PT_DEV void traverse_round4(const float4* nodes4, const float4* tris, const Stac
   best = w.best;
 }
 
-// ---- pools of fresh paths shared by the waves of a workgroup (LDS)
-//
-// Each wave owns a pool of 64 fresh paths (one 8x8 tile, pool_store_lds), but ANY wave of the workgroup may take entries
-// from it: a pool's read cursor lives in LDS and entries are claimed with one ds_add_rtn.  A wave takes a new tile ticket
-// only when every pool of its workgroup is empty, so a workgroup buffers about one tile of fresh paths instead of one per
-// wave, and when the tickets of a launch run out no wave sits on half a tile while its neighbours' lanes idle: the waves
-// of a workgroup run dry together (profiles/r03_tail_*: wave exit times before / after).
-// Layout behind p.pool_lds_offset, NW = waves per workgroup:
-//   entries  NW x 576 dwords (pool_store_lds)
-//   cursor   NW dwords   entries [cursor, 64) of pool w are unclaimed (>= 64: empty); only the owner ever resets it to 0
-//   busy     NW dwords   waves other than the owner that are reading pool w right now: the owner refills only at busy == 0
-//   desc     NW x 4      tile_x0, tile_y0, frame k, tile_row_delta of the tile in pool w
-typedef __attribute__((address_space(3))) uint32_t* LdsWord;
-PT_DEV LdsWord lds_word(const void* base, uint32_t dword) { return (LdsWord)(uintptr_t)((uint32_t)(uintptr_t)base + dword * 4u); }
-PT_DEV uint32_t lds_atomic_add(LdsWord q, uint32_t v) { return __hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-PT_DEV uint32_t lds_load(LdsWord q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-PT_DEV void lds_store(LdsWord q, uint32_t v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// per-wave time stamps of a launch (ptamd_set_timeline): [4 gwave + slot] = 100 MHz device clock at 0 kernel entry, 1 scene staged,
-// 2 the first time the wave found no ticket, 3 exit
+// per-wave time stamps of a launch (ptamd_set_timeline): [4 gwave + slot] = device clock at 0 kernel entry, 1 scene staged,
+// 2 the wave found no ticket (tail mode from here on), 3 exit
+// (an instantiation of its own, VARIANT == PT_RS_STAMPS: even switched off the four stamps cost the round loop 1.5 %)
 #define PT_STAMP(slot)                                                                                                   \
   do {                                                                                                                   \
-    unsigned long long* tl_ = PT_KARG(p, timeline);                                                                      \
-    if (tl_ && (threadIdx.x & 63u) == 0u)                                                                                \
-      tl_[(size_t)(blockIdx.x * (THREADS / 64u) + (threadIdx.x >> 6)) * 4u + (slot)] = wall_clock64();                   \
+    if (VARIANT == PT_RS_STAMPS) {                                                                                       \
+      unsigned long long* tl_ = PT_KARG(p, timeline);   /* (loaded by the whole wave: scalar) */                         \
+      if ((threadIdx.x & 63u) == 0u)                                                                                     \
+        tl_[(size_t)(blockIdx.x * (THREADS / 64u) + (threadIdx.x >> 6)) * 4u + (slot)] = wall_clock64();                 \
+    }                                                                                                                    \
   } while (0)
+// instantiations of the restart kernel: the shipped one, the instrumented one (counters), the one that records per-wave time
+// stamps, and the one that tests every triangle instead of walking the tree (far-origin launches, ptamd_api.cpp)
+#define PT_RS_PLAIN 0
+#define PT_RS_STATS 1
+#define PT_RS_STAMPS 2
+#define PT_RS_BRUTE 3
 
 // KParams must stay this kernel's first by-value argument: PT_KARG reads its fields from the kernel-argument segment.
-template <bool LDS_RESIDENT, bool STATS>
+template <bool LDS_RESIDENT, int VARIANT>
 __global__ void __launch_bounds__(LDS_RESIDENT ? PT_RS_THREADS : PT_RS4_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_EU : PT_RS4_WAVES_PER_EU)
 pt_megakernel_restart(const KParams p)
 {
+  constexpr bool STATS = VARIANT == PT_RS_STATS;
   constexpr uint32_t THREADS = LDS_RESIDENT ? PT_RS_THREADS : PT_RS4_THREADS;
-  constexpr uint32_t NW = THREADS / 64u;
   extern __shared__ float4 s_mem[];
   const float4* s_nodes;
   const float4* s_tris;
   PT_STAMP(0);
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t my_wave = threadIdx.x >> 6;
-  // the pool area (entries, then cursors / reader counts / tile descriptors) sits p.pool_lds_offset bytes into the dynamic LDS;
-  // scenes that leave no room for the entries keep those in a global slab (p.pool_in_lds == 0), the header stays in LDS
-  if (lane == 0u) {
-    const char* pools_base = reinterpret_cast<const char*>(s_mem) + p.pool_lds_offset;
-    const uint32_t HDR = p.pool_in_lds ? NW * 576u : 0u;         // dword offset of the cursor array inside the pool area
-    lds_store(lds_word(pools_base, HDR + my_wave), 64u);         // empty
-    lds_store(lds_word(pools_base, HDR + NW + my_wave), 0u);     // no reader
-  }
   stage_scene<2, LDS_RESIDENT, LDS_RESIDENT && !STATS && PT_ASM_WALK>(p, s_mem, s_nodes, s_tris);
   // scenes that do not fit in LDS are walked in the four-wide form; LDS then holds the waves' stacks
   constexpr bool WIDE = !LDS_RESIDENT;
 
-  const uint32_t gwave = blockIdx.x * NW + my_wave;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t gwave = blockIdx.x * (THREADS / 64u) + (threadIdx.x >> 6);
+  float4* slab = p.pool + (size_t)gwave * 192u;
+  // p.pool_lds_offset != 0: the pools live in LDS behind the staged scene (576 dwords per wave) instead of the global slab
+  uint32_t* lds_pool = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_mem) + p.pool_lds_offset) + (threadIdx.x >> 6) * 576u;
   Stack4 stk;
   stk.top = s_mem;
   stk.top_n = WIDE ? p.treelet_nodes : 0u;
@@ -1385,7 +1370,7 @@ pt_megakernel_restart(const KParams p)
     __syncthreads();
   }
   PT_STAMP(1);
-  stk.lds = reinterpret_cast<uint2*>(s_mem + (size_t)p.treelet_nodes * 8u) + (size_t)my_wave * p.stack_lds_entries * 64u + lane;
+  stk.lds = reinterpret_cast<uint2*>(s_mem + (size_t)p.treelet_nodes * 8u) + (size_t)(threadIdx.x >> 6) * p.stack_lds_entries * 64u + lane;
   stk.spill = p.stack_spill + (size_t)gwave * p.stack_spill_entries * 64u + lane;
   stk.lds_entries = p.stack_lds_entries;
   uint32_t cur = PT_NONE, sp = 0;   // wide walk: reference to process next, entries on the stack
@@ -1401,144 +1386,96 @@ pt_megakernel_restart(const KParams p)
   Best best;
   best.t = PT_MAX_DIST; best.u = best.v = 0.f; best.idx = PT_END;
   uint32_t node = PT_END;
-  // wave-uniform: the ticket this wave is expanding into tiles
+  // wave-uniform: the pool holds the paths of ONE tile, entries [pool_rd, 64) not yet handed out
+  uint32_t pool_rd = 64u, tile_x0 = 0, tile_y0 = 0, tile_k = 0;
+  uint32_t tile_row_delta = 0;   // (frame row) - (row of the launch's buffers + row_begin): non-zero for interleaved bands
   uint32_t tile = 0, tile_end = 0;
   uint32_t ticket = gwave;
   uint32_t head = blockIdx.x & 7u, dry = 0;
   bool have_ticket = true, exhausted = false;
-
-  // next (tile, frame) of this wave: its own first ticket, then the XCD's ticket head (a dry head sends the wave on to the
-  // next one for good).  false: the launch has no tile left.
-  auto next_tile = [&](uint32_t& tile_x0, uint32_t& tile_y0, uint32_t& tile_k, uint32_t& tile_row_delta) -> bool {
-    if (tile >= tile_end) {
-      const uint32_t tiles_per_ticket = PT_KARG(p, tiles_per_ticket);
-      const uint32_t total = PT_KARG(p, n_tiles) * PT_KARG(p, sample_count); // (tile, frame) pairs
-      if (!have_ticket) {
-        uint32_t* heads = PT_KARG(p, tile_heads);
-        const uint32_t n_static = PT_KARG(p, n_static);
-        for (;;) {
-          uint32_t t = 0;
-          if (lane == 0) t = atomicAdd(heads + head * PT_HEAD_STRIDE, 1u);
-          t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-          ticket = n_static + t * 8u + head;
-          if ((unsigned long long)ticket * tiles_per_ticket < total) break;
-          head = (head + 1u) & 7u;
-          if (++dry == 8u) break;
-        }
-        if (dry == 8u) return false;
-      }
-      have_ticket = false;
-      tile = ticket * tiles_per_ticket;
-      if (tile >= total) return false;
-      tile_end = tile + tiles_per_ticket;
-      if (tile_end > total) tile_end = total;
-    }
-    const uint32_t n_tiles = PT_KARG(p, n_tiles), tiles_x = PT_KARG(p, tiles_x), row_begin = PT_KARG(p, row_begin);
-    tile_k = tile / n_tiles;
-    const uint32_t tl = tile - tile_k * n_tiles;
-    tile_x0 = (tl % tiles_x) * PT_TILE_W;
-    const uint32_t local_y0 = (tl / tiles_x) * PT_TILE_H;   // row inside this launch's share of the frame
-    const uint32_t ilv_ranks = PT_KARG(p, ilv_ranks);
-    if (ilv_ranks > 1u) {
-      // interleaved bands: band j of ilv_rows rows belongs to rank j % ilv_ranks; this launch renders
-      // the bands of rank ilv_rank and stores them one after the other
-      const uint32_t ilv_rows = PT_KARG(p, ilv_rows);
-      const uint32_t b = local_y0 / ilv_rows, within = local_y0 - b * ilv_rows;
-      tile_y0 = (b * ilv_ranks + PT_KARG(p, ilv_rank)) * ilv_rows + within;
-    } else {
-      tile_y0 = row_begin + local_y0;
-    }
-    tile_row_delta = tile_y0 - (row_begin + local_y0);
-    ++tile;
-    return true;
-  };
   for (;;) {
-    // ---- restart lanes without a path from a pool of the workgroup; an empty pool is refilled with a whole tile, all lanes active
+    // ---- restart lanes without a path from the pool; an empty pool is refilled with a whole tile, all lanes active
     unsigned long long need = __ballot(idle);
-    if (need) {
-      // (rare next to the walk: everything this block needs is re-read from the kernel arguments rather than kept in registers)
-      const char* pools_base = reinterpret_cast<const char*>(s_mem) + PT_KARG(p, pool_lds_offset);
-      const bool entries_in_lds = PT_KARG(p, pool_in_lds) != 0u;
-      const uint32_t HDR = entries_in_lds ? NW * 576u : 0u;   // dword offset of the cursor array inside the pool area
-      const uint32_t my_wave = threadIdx.x >> 6;
-      uint32_t v = my_wave;   // the pool to try next: this wave's own first
-      for (;;) {
-        // claim entries of pool v for the idle lanes
-        {
-          const bool own = v == my_wave;
-          const uint32_t wanted = (uint32_t)__popcll(need);
-          uint32_t old = 0;
-          if (lane == 0u) {
-            if (!own) lds_atomic_add(lds_word(pools_base, HDR + NW + v), 1u);
-            old = lds_atomic_add(lds_word(pools_base, HDR + v), wanted);
-          }
-          old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-          if (old < 64u) {
-            const uint32_t x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(lds_word(pools_base, HDR + 2u * NW + v * 4u + 0u)));
-            const uint32_t y0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(lds_word(pools_base, HDR + 2u * NW + v * 4u + 1u)));
-            const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(lds_word(pools_base, HDR + 2u * NW + v * 4u + 2u)));
-            const uint32_t delta = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_load(lds_word(pools_base, HDR + 2u * NW + v * 4u + 3u)));
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            const uint32_t e = old + rank;
-            const uint32_t x = x0 + (e & (PT_TILE_W - 1u)), y = y0 + (e >> PT_TILE_W_LOG2);
-            // entries of pixels outside the frame were never written: their lanes stay idle and ask again
-            if (idle && e < 64u && x < PT_KARG(p, width) && y < PT_KARG(p, y_limit)) {
-              if (entries_in_lds) pool_load_lds(reinterpret_cast<const uint32_t*>(pools_base) + v * 576u, e, st);
-              else pool_load(PT_KARG(p, pool) + (size_t)(blockIdx.x * NW + v) * 192u, e, st);
-              st.throughput = mk3(1.0f);
-              st.acc = mk3(0.0f);
-              st.specular_col = 0.0f;
-              // the path is done with its frame coordinates (seed and ray were made in path_begin): from here on `y` is
-              // the row its sample is parked at, row_begin + the row inside the launch's buffers
-              st.xy = x | ((y - delta) << 16);
-              st.bk = k << 16;
-              idle = false;
-              walking = false;
-            }
-          }
-          if (!own) {
-            // this wave's reads of pool v have returned before its owner may overwrite the entries
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            if (lane == 0u) lds_atomic_add(lds_word(pools_base, HDR + NW + v), 0xFFFFFFFFu);
-          }
-          need = __ballot(idle);
-        }
-        if (!need) break;
-        // any pool of the workgroup with unclaimed entries?  (lane w looks at pool w; start behind this wave so that the
-        // idle waves of a workgroup do not all fall on the same neighbour)
-        const uint32_t c = lane < NW ? lds_load(lds_word(pools_base, HDR + lane)) : 64u;
-        const unsigned long long nonempty = __ballot(c < 64u);
-        if (nonempty && PT_KARG(p, pool_share)) {
-          const unsigned long long behind = nonempty & ~((2ull << my_wave) - 1ull);
-          v = (uint32_t)__builtin_ctzll(behind ? behind : nonempty);
-          continue;
-        }
+    while (need) {
+      if (pool_rd >= 64u) {
         if (exhausted) break;
-        // every pool is empty: this wave makes the 64 paths of the launch's next tile in its own pool
-        uint32_t tile_x0, tile_y0, tile_k, tile_row_delta;
-        if (!next_tile(tile_x0, tile_y0, tile_k, tile_row_delta)) { exhausted = true; PT_STAMP(2); break; }
-        // nobody may still be reading the previous tile's entries
-        while (lds_load(lds_word(pools_base, HDR + NW + my_wave)) != 0u) __builtin_amdgcn_s_sleep(1);
+        if (tile >= tile_end) {
+          const uint32_t tiles_per_ticket = PT_KARG(p, tiles_per_ticket);
+          const uint32_t total = PT_KARG(p, n_tiles) * PT_KARG(p, sample_count); // (tile, frame) pairs
+          if (!have_ticket) {
+            uint32_t* heads = PT_KARG(p, tile_heads);
+            const uint32_t n_static = PT_KARG(p, n_static);
+            for (;;) {
+              uint32_t t = 0;
+              if (lane == 0) t = atomicAdd(heads + head * PT_HEAD_STRIDE, 1u);
+              t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+              ticket = n_static + t * 8u + head;
+              if ((unsigned long long)ticket * tiles_per_ticket < total) break;
+              head = (head + 1u) & 7u;
+              if (++dry == 8u) break;
+            }
+            if (dry == 8u) { exhausted = true; PT_STAMP(2); break; }
+          }
+          have_ticket = false;
+          tile = ticket * tiles_per_ticket;
+          if (tile >= total) { exhausted = true; PT_STAMP(2); break; }
+          tile_end = tile + tiles_per_ticket;
+          if (tile_end > total) tile_end = total;
+        }
+        {
+          const uint32_t n_tiles = PT_KARG(p, n_tiles), tiles_x = PT_KARG(p, tiles_x), row_begin = PT_KARG(p, row_begin);
+          tile_k = tile / n_tiles;
+          const uint32_t tl = tile - tile_k * n_tiles;
+          tile_x0 = (tl % tiles_x) * PT_TILE_W;
+          const uint32_t local_y0 = (tl / tiles_x) * PT_TILE_H;   // row inside this launch's share of the frame
+          const uint32_t ilv_ranks = PT_KARG(p, ilv_ranks);
+          if (ilv_ranks > 1u) {
+            // interleaved bands: band j of ilv_rows rows belongs to rank j % ilv_ranks; this launch renders
+            // the bands of rank ilv_rank and stores them one after the other
+            const uint32_t ilv_rows = PT_KARG(p, ilv_rows);
+            const uint32_t b = local_y0 / ilv_rows, within = local_y0 - b * ilv_rows;
+            tile_y0 = (b * ilv_ranks + PT_KARG(p, ilv_rank)) * ilv_rows + within;
+          } else {
+            tile_y0 = row_begin + local_y0;
+          }
+          tile_row_delta = tile_y0 - (row_begin + local_y0);
+        }
+        ++tile;
         {
           const uint32_t x = tile_x0 + (lane & (PT_TILE_W - 1u)), y = tile_y0 + (lane >> PT_TILE_W_LOG2);
-          if (x < PT_KARG(p, width) && y < PT_KARG(p, y_limit)) {
+          if (x < p.width && y < p.y_limit) {
             Path fresh;
             path_begin(p, x, y, fresh, tile_k);
-            if (entries_in_lds) pool_store_lds(reinterpret_cast<uint32_t*>(const_cast<char*>(pools_base)) + my_wave * 576u, lane, fresh);
-            else pool_store(PT_KARG(p, pool) + (size_t)(blockIdx.x * NW + my_wave) * 192u, lane, fresh);
+            if (p.pool_lds_offset) pool_store_lds(lds_pool, lane, fresh);
+            else pool_store(slab, lane, fresh);
           }
-          if (lane == 0u) {
-            lds_store(lds_word(pools_base, HDR + 2u * NW + my_wave * 4u + 0u), tile_x0);
-            lds_store(lds_word(pools_base, HDR + 2u * NW + my_wave * 4u + 1u), tile_y0);
-            lds_store(lds_word(pools_base, HDR + 2u * NW + my_wave * 4u + 2u), tile_k);
-            lds_store(lds_word(pools_base, HDR + 2u * NW + my_wave * 4u + 3u), tile_row_delta);
-          }
-          // entries (global slab: they have reached L2) and descriptor are in place before the cursor says so
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          if (lane == 0u) lds_store(lds_word(pools_base, HDR + my_wave), 0u);
+          // the stores have reached L2 (LDS: are ordered before this wave's later reads) before any lane reads them back
+          if (!p.pool_lds_offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        v = my_wave;
+        pool_rd = 0u;
       }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+      const uint32_t avail = 64u - pool_rd;
+      if (idle && rank < avail) {
+        const uint32_t e = pool_rd + rank;
+        const uint32_t x = tile_x0 + (e & (PT_TILE_W - 1u)), y = tile_y0 + (e >> PT_TILE_W_LOG2);
+        if (x < p.width && y < p.y_limit) {   // entries of pixels outside the frame were never written: skip them
+          if (p.pool_lds_offset) pool_load_lds(lds_pool, e, st);
+          else pool_load(slab, e, st);
+          st.throughput = mk3(1.0f);
+          st.acc = mk3(0.0f);
+          st.specular_col = 0.0f;
+          // the path is done with its frame coordinates (seed and ray were made in path_begin): from here on `y` is
+          // the row its sample is parked at, row_begin + the row inside the launch's buffers
+          st.xy = x | ((y - tile_row_delta) << 16);
+          st.bk = tile_k << 16;
+          idle = false;
+          walking = false;
+        }
+      }
+      const uint32_t wanted = (uint32_t)__popcll(need);
+      pool_rd += wanted < avail ? wanted : avail;
+      need = __ballot(idle);
     }
     if (__ballot(!idle) == 0ull) break;
 
@@ -1551,7 +1488,7 @@ pt_megakernel_restart(const KParams p)
         walking = true;
         if (STATS) cnt.rays++;
       }
-      if (p.brute_walk) {
+      if (VARIANT == PT_RS_BRUTE) {
         // a camera too far outside the scene for the boxes' margins (ptamd_api.cpp: far_origin): every triangle record, as
         // the reference does — the (t, face index) minimum does not depend on the order they are tested in
         for (uint32_t i = 0; i < p.n_bvh_tris; ++i) mt_test<false>(s_tris[i * 3u], s_tris[i * 3u + 1u], s_tris[i * 3u + 2u], st.o, st.d, best, false);
@@ -2154,13 +2091,22 @@ hipError_t launch_megakernel_persistent(const KParams& p, bool lds_resident, siz
   return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_PERSISTENT_THREADS), args, lds_bytes, stream);
 }
 
-static const void* restart_select(bool lds_resident, bool stats)
+template <bool LDS_RES>
+static const void* restart_entry(int variant)
 {
-  if (lds_resident)
-    return stats ? reinterpret_cast<const void*>(pt_megakernel_restart<true, true>)
-                 : reinterpret_cast<const void*>(pt_megakernel_restart<true, false>);
-  return stats ? reinterpret_cast<const void*>(pt_megakernel_restart<false, true>)
-               : reinterpret_cast<const void*>(pt_megakernel_restart<false, false>);
+  switch (variant) {
+    case PT_RS_STATS: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_STATS>);
+    case PT_RS_STAMPS: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_STAMPS>);
+    case PT_RS_BRUTE: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_BRUTE>);
+    default: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_PLAIN>);
+  }
+}
+
+// variant: instrumented build when counters are wanted, else the far-origin form, else the time-stamp form, else the shipped kernel
+static const void* restart_select(bool lds_resident, bool stats, const KParams* p = nullptr)
+{
+  const int variant = stats ? PT_RS_STATS : (p && p->brute_walk ? PT_RS_BRUTE : (p && p->timeline ? PT_RS_STAMPS : PT_RS_PLAIN));
+  return lds_resident ? restart_entry<true>(variant) : restart_entry<false>(variant);
 }
 
 uint32_t restart_threads(bool lds_resident) { return lds_resident ? PT_RS_THREADS : PT_RS4_THREADS; }
@@ -2182,7 +2128,7 @@ hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t
                                      uint32_t n_blocks, hipStream_t stream)
 {
   if (p.n_tiles == 0 || n_blocks == 0) return hipSuccess;
-  const void* fn = restart_select(lds_resident, stats);
+  const void* fn = restart_select(lds_resident, stats, &p);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -2307,7 +2253,8 @@ hipError_t resolve_kernels()
   const void* fns[] = {
     persistent_select(true, false), persistent_select(false, false), persistent_select(true, true), persistent_select(false, true),
     split_select(true, false), split_select(false, false), blockwise_select(true, false), blockwise_select(false, false),
-    restart_select(true, false), restart_select(false, false), restart_select(true, true), restart_select(false, true),
+    restart_entry<true>(PT_RS_PLAIN), restart_entry<false>(PT_RS_PLAIN), restart_entry<true>(PT_RS_STATS), restart_entry<false>(PT_RS_STATS),
+    restart_entry<true>(PT_RS_STAMPS), restart_entry<false>(PT_RS_STAMPS), restart_entry<true>(PT_RS_BRUTE), restart_entry<false>(PT_RS_BRUTE),
     reinterpret_cast<const void*>(pt_megakernel<1, true, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_megakernel<1, false, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_megakernel<2, true, false, PT_TILE_THREADS>),

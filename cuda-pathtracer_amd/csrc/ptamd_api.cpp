@@ -73,17 +73,20 @@ struct ptamd_context {
   struct Occupancy { size_t lds = ~(size_t)0; int blocks_per_cu = -1; } occupancy[4];
   // parked samples of batched launches, one scratch per stream: launches on one stream are ordered, launches on
   // different streams of one context (frames in flight, ptamd_launch.machine_share) must not share a buffer
-  // Three slabs per stream.  [0], [1] are used in turn by launches whose megakernel runs on an internal stream (below), so
-  // that the megakernel of launch N+1 can write its samples while the resolve pass of launch N still reads its own; [2]
-  // belongs to launches that stay on the caller's stream from start to end (captured into a graph, instrumented, or part
-  // of the caller's own pipeline): stream order alone protects it, also against replays of a captured launch.
+  // Four slabs per stream.  [0..2] are used in turn by pipelined launches (megakernel on an internal stream, below): the
+  // megakernel of launch N+1 writes its samples while the resolve pass of launch N still reads its own, and with three of
+  // them the megakernel of launch N+2 — next on launch N's internal stream — does not have to wait for that resolve pass
+  // either (two slabs: a 60 us bubble per launch, two event hops and the pass itself); [3] belongs to launches that stay on
+  // the caller's stream from start to end (one at a time, captured into a graph, instrumented, or part of the caller's own
+  // pipeline): stream order alone protects it, also against replays of a captured launch.
   struct SampleScratch {
     void* stream = nullptr;
-    float* buf[3] = { nullptr, nullptr, nullptr };
-    size_t bytes[3] = { 0, 0, 0 };
-    hipEvent_t mega_done[2] = { nullptr, nullptr };   // megakernel of the last launch that used slab i has finished
-    hipEvent_t resolved[2] = { nullptr, nullptr };    // resolve pass of the last launch that used slab i has finished
-    bool resolved_valid[2] = { false, false };
+    float* buf[4] = { nullptr, nullptr, nullptr, nullptr };
+    size_t bytes[4] = { 0, 0, 0, 0 };
+    hipEvent_t mega_done[3] = { nullptr, nullptr, nullptr };   // megakernel of the last launch that used slab i has finished
+    hipEvent_t resolved[3] = { nullptr, nullptr, nullptr };    // resolve pass of the last launch that used slab i has finished
+    bool resolved_valid[3] = { false, false, false };
+    hipEvent_t last_done = nullptr;                   // recorded behind every launch of this stream: is the host running ahead?
     uint32_t flip = 0;
   };
   std::vector<SampleScratch> sample_scratch;
@@ -94,7 +97,6 @@ struct ptamd_context {
   // a host that simply calls raytrace() again without synchronising (gpu_processor.cpp:365-386 does not).
   hipStream_t internal[2] = { nullptr, nullptr };
   bool overlap = true;                    // PTAMD_OVERLAP=0 (tuning): everything on the caller's stream
-  bool pool_share = true;                 // PTAMD_POOL_SHARE=0 (tuning): waves take fresh paths from their own pool only
   unsigned long long* d_timeline = nullptr;   // ptamd_set_timeline: 4 time stamps per wave of the restart kernel
   uint32_t timeline_waves = 0;
   uint32_t default_kernel = PTAMD_KERNEL_BVH_RESTART; // what PTAMD_KERNEL_AUTO means
@@ -171,11 +173,12 @@ void free_scene(DeviceScene& s)
 
 void free_scratch(ptamd_context::SampleScratch& c)
 {
-  for (int i = 0; i < 3; ++i) (void)hipFree(c.buf[i]);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 4; ++i) (void)hipFree(c.buf[i]);
+  for (int i = 0; i < 3; ++i) {
     if (c.mega_done[i]) (void)hipEventDestroy(c.mega_done[i]);
     if (c.resolved[i]) (void)hipEventDestroy(c.resolved[i]);
   }
+  if (c.last_done) (void)hipEventDestroy(c.last_done);
   c = ptamd_context::SampleScratch();
 }
 
@@ -296,19 +299,43 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   // the LDS copy of a BVH addresses its boxes with 15 bits (pt_kernels.hip: stage_scene): 32 bytes per node, nodes first
   const bool resident = lds <= kLdsBudget && (kind == 1 || s.n_nodes <= kCompactMaxNodes);
   hipStream_t stream = static_cast<hipStream_t>(l->stream);
-  // Consecutive launches of the restart kernel on one stream overlap (ptamd_context::internal) unless the caller runs its
-  // own pipeline (machine_share > 1: several streams, each launch sized to its share), captures a graph, or wants counters
-  bool overlap = ctx->overlap && which == PTAMD_KERNEL_BVH_RESTART && l->machine_share <= 1u && !stats;
-  if (overlap && stream != nullptr) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) overlap = false;
+  // Per-stream state of the persistent kernels: sample slabs, events (found or made here, once per launch)
+  ptamd_context::SampleScratch* sc = nullptr;
+  if (which == PTAMD_KERNEL_BVH_PERSISTENT || which == PTAMD_KERNEL_BVH_SPLIT || which == PTAMD_KERNEL_BVH_RESTART) {
+    for (auto& c : ctx->sample_scratch) if (c.stream == l->stream) sc = &c;
+    if (!sc) {
+      if (ctx->sample_scratch.size() >= kMaxScratchStreams) {
+        // a host cycling through short-lived streams: drop every scratch once nothing can be using them
+        PT_HIP(hipDeviceSynchronize());
+        for (auto& c : ctx->sample_scratch) free_scratch(c);
+        ctx->sample_scratch.clear();
+      }
+      ctx->sample_scratch.emplace_back();
+      sc = &ctx->sample_scratch.back();
+      sc->stream = l->stream;
+    }
   }
+  // Launches of the restart kernel that a host issues back to back on one stream are pipelined by the library
+  // (ptamd_context::internal): when the previous launch of this stream has not finished yet — the host is running ahead —
+  // this one is sized to half the GPU and its megakernel goes to an internal stream, so that the two are resident side by
+  // side and the tail of one is covered by the bulk of the other, exactly what a host gets from two streams and
+  // machine_share = 2.  Not when the caller runs its own pipeline (machine_share > 1), captures a graph or wants counters;
+  // a host that waits for every frame gets whole-GPU launches on its own stream as before.
+  bool pipelined = ctx->overlap && which == PTAMD_KERNEL_BVH_RESTART && l->machine_share <= 1u && !stats;
+  bool capturing = false;
+  if (stream != nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) capturing = true;
+  }
+  if (capturing) pipelined = false;
+  if (pipelined) pipelined = sc->last_done != nullptr && hipEventQuery(sc->last_done) == hipErrorNotReady;
   // PTAMD_KERNEL_AUTO, one frame per launch (the reference's interactive loop, ptamd_raytrace) on an LDS-resident scene,
-  // when launches cannot overlap: the persistent kernel writes the surface itself, the restart kernel would add its
-  // resolve pass to every launch (1080p, one launch per spp, one at a time: 6.03 vs 5.89 Gsamples/s).
+  // one launch at a time: the persistent kernel writes the surface itself, the restart kernel would add its resolve
+  // pass to every launch (1080p, one launch per spp, one at a time: 6.03 vs 5.89 Gsamples/s).
   if (l->kernel == PTAMD_KERNEL_AUTO && which == PTAMD_KERNEL_BVH_RESTART && ctx->default_kernel_is_builtin && l->frame_count <= 1 &&
-      resident && l->interleave_ranks <= 1 && l->machine_share <= 1 && !overlap && !p.brute_walk)
+      resident && l->interleave_ranks <= 1 && l->machine_share <= 1 && !pipelined && !p.brute_walk)
     which = PTAMD_KERNEL_BVH_PERSISTENT;
+  const bool overlap = pipelined;
   hipError_t e;
   if (far_origin && !p.brute_walk && l->frame_count > 1) {
     // batched frames == consecutive launches by contract: issue them that way
@@ -381,7 +408,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       // the top of the tree (breadth-first numbering: nodes 0..340 are its first five levels when full) goes to LDS too:
       // 512 nodes = 64 KB of the one workgroup's 160 KB, then 7 stack entries per lane
       // ... and the waves' pools of fresh paths (PT_POOL_LDS_BYTES each), behind the stacks
-      const uint32_t pools = waves * (ctx->pool_in_lds ? PT_POOL_LDS_BYTES : PT_POOL_HDR_BYTES);   // (global-slab entries: only the header)
+      const uint32_t pools = ctx->pool_in_lds ? waves * PT_POOL_LDS_BYTES : 0u;
       uint32_t treelet = ctx->treelet_nodes < s.n_nodes4 ? ctx->treelet_nodes : s.n_nodes4;
       if (treelet * 128u + waves * 512u * 4u + pools > share) treelet = (share - pools - waves * 512u * 4u) / 128u;   // keep >= 4 stack entries
       uint32_t fit = (share - pools - treelet * 128u) / (waves * 512u);
@@ -390,9 +417,11 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       p.stack_lds_entries = need < fit ? need : fit;
       p.stack_spill_entries = need - p.stack_lds_entries;
       launch_lds = (size_t)treelet * 128u + (size_t)p.stack_lds_entries * waves * 512u;
-      p.pool_lds_offset = (uint32_t)launch_lds;
-      p.pool_in_lds = ctx->pool_in_lds ? 1u : 0u;
-      launch_lds = p.pool_lds_offset + pools;
+      if (pools) {
+        p.pool_lds_offset = (uint32_t)launch_lds;
+        if (!p.pool_lds_offset) p.pool_lds_offset = 16u;
+        launch_lds = p.pool_lds_offset + pools;
+      }
     }
     if (restart && resident) {
       // pools of fresh paths in LDS when two workgroups with their scene copies leave room for them (PT_POOL_LDS_BYTES
@@ -400,11 +429,11 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       const uint32_t waves = restart_threads(true) / 64u;
       const size_t with_pools = ((lds + 15u) & ~(size_t)15u) + (size_t)waves * PT_POOL_LDS_BYTES;
       const size_t blocks_wanted = (24u + waves - 1u) / waves;             // 24 waves per CU
-      p.pool_lds_offset = (uint32_t)((lds + 15u) & ~(size_t)15u);
-      p.pool_in_lds = (ctx->pool_in_lds && with_pools * blocks_wanted + 1024u <= 160u * 1024u) ? 1u : 0u;
-      // (the header — read cursors, reader counts, tile descriptors: 32 bytes per wave — always fits: a resident scene takes
-      // at most 64 KB of a workgroup's 80)
-      launch_lds = p.pool_lds_offset + (size_t)waves * (p.pool_in_lds ? PT_POOL_LDS_BYTES : PT_POOL_HDR_BYTES);
+      if (ctx->pool_in_lds && with_pools * blocks_wanted + 1024u <= 160u * 1024u) {
+        p.pool_lds_offset = (uint32_t)((lds + 15u) & ~(size_t)15u);
+        if (p.pool_lds_offset == 0) p.pool_lds_offset = 16u;               // (an empty scene: keep the flag non-zero)
+        launch_lds = p.pool_lds_offset + (size_t)waves * PT_POOL_LDS_BYTES;
+      }
     }
     ptamd_context::Occupancy& occ = ctx->occupancy[split ? 2 : (restart ? 3 : 0)];
     const size_t occ_key = resident ? (restart ? launch_lds : lds) : (restart ? launch_lds + 1u : 0);
@@ -426,7 +455,8 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     // 6: 3.44 vs 3.92, 8: 2.89 vs 3.71); below that, whole-wave refill keeps primary rays coherent.
     p.refill_min = ctx->refill_min ? ctx->refill_min : (l->bounces >= 5 ? 16u : 64u);
     const uint32_t tiles_per_ticket = ctx->tiles_per_ticket;
-    if (l->machine_share > 1u) n_blocks = n_blocks / l->machine_share > 0u ? n_blocks / l->machine_share : 1u;
+    const uint32_t share = overlap ? 2u : l->machine_share;
+    if (share > 1u) n_blocks = n_blocks / share > 0u ? n_blocks / share : 1u;
     const uint32_t n_tickets = (p.n_tiles * count + tiles_per_ticket - 1u) / tiles_per_ticket;
     const uint32_t useful = (n_tickets + waves_per_block - 1u) / waves_per_block;
     if (n_blocks > useful) n_blocks = useful;
@@ -436,36 +466,22 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     // the restart kernel parks every sample (also of a single frame: pt_resolve_kernel accumulates and tonemaps) and
     // keeps a 3 KiB pool of fresh paths per wave
     const bool parks = count > 1 || restart;
-    ptamd_context::SampleScratch* sc = nullptr;
     uint32_t scratch_slab = 0;
     if (parks) {
       const size_t sample_bytes = ((size_t)count * rows * l->width * 3u * sizeof(float) + 255u) & ~(size_t)255u;
-      const size_t pool_bytes = (restart && !p.pool_in_lds) ? (size_t)n_blocks * waves_per_block * 192u * sizeof(float4) : 0u;
+      const size_t pool_bytes = (restart && !p.pool_lds_offset) ? (size_t)n_blocks * waves_per_block * 192u * sizeof(float4) : 0u;
       const size_t spill_bytes = (size_t)n_blocks * waves_per_block * p.stack_spill_entries * 512u;
       const size_t need = sample_bytes + pool_bytes + spill_bytes + 16u;
       uint32_t& slab = scratch_slab;
-      for (auto& c : ctx->sample_scratch) if (c.stream == l->stream) sc = &c;
-      if (!sc) {
-        if (ctx->sample_scratch.size() >= kMaxScratchStreams) {
-          // a host cycling through short-lived streams: drop every scratch once nothing can be using them
-          PT_HIP(hipDeviceSynchronize());
-          for (auto& c : ctx->sample_scratch) free_scratch(c);
-          ctx->sample_scratch.clear();
-        }
-        ctx->sample_scratch.emplace_back();
-        sc = &ctx->sample_scratch.back();
-        sc->stream = l->stream;
-      }
-      slab = overlap ? (sc->flip++ & 1u) : 2u;
-      if (overlap && !ctx->internal[slab]) PT_HIP(hipStreamCreateWithFlags(&ctx->internal[slab], hipStreamNonBlocking));
-      for (int i = 0; i < 2 && overlap; ++i) {
+      slab = overlap ? sc->flip % 3u : 3u;
+      for (int i = 0; i < 3 && overlap; ++i) {
         if (!sc->mega_done[i]) PT_HIP(hipEventCreateWithFlags(&sc->mega_done[i], hipEventDisableTiming));
         if (!sc->resolved[i]) PT_HIP(hipEventCreateWithFlags(&sc->resolved[i], hipEventDisableTiming));
       }
-      // the slab of this launch, and with it the in-stream slab: a launch captured into a graph later must find its scratch
-      // sized already (allocating would break the capture), whichever way the launches before it went
-      for (uint32_t i : { slab, 2u }) {
-        if (need <= sc->bytes[i]) continue;
+      // all three slabs grow together (allocating synchronises: it must not happen when a host that had waited for its
+      // frames starts to run ahead, nor inside a graph capture that follows an eager launch of the same configuration)
+      for (uint32_t i = 0; i < 4u; ++i) {
+        if (need <= sc->bytes[i] || (!ctx->overlap && i != 3u)) continue;
         // launches of this stream (their megakernels possibly on the internal streams) are the only users of the old buffer
         PT_HIP(hipStreamSynchronize(stream));
         for (hipStream_t is : ctx->internal) if (is) PT_HIP(hipStreamSynchronize(is));
@@ -478,7 +494,6 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       p.pool = reinterpret_cast<float4*>(reinterpret_cast<char*>(sc->buf[slab]) + sample_bytes);
       p.stack_spill = reinterpret_cast<uint2*>(reinterpret_cast<char*>(sc->buf[slab]) + sample_bytes + pool_bytes);
     }
-    p.pool_share = ctx->pool_share ? 1u : 0u;
     p.round_min = ctx->round_min;
     p.round_div = ctx->round_div;
     p.walk_min = ctx->walk_min;
@@ -493,7 +508,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     if (overlap) {
       // the megakernel touches nothing of the caller's: it may start before earlier work on the caller's stream has finished,
       // as soon as the slab's previous reader (the resolve pass two launches back) is done
-      mega_stream = ctx->internal[scratch_slab];
+      mega_stream = ctx->internal[sc->flip++ & 1u];
       if (sc->resolved_valid[scratch_slab]) PT_HIP(hipStreamWaitEvent(mega_stream, sc->resolved[scratch_slab], 0));
     }
     if (!split) {
@@ -519,6 +534,10 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
         PT_HIP(hipEventRecord(sc->resolved[scratch_slab], stream));
         sc->resolved_valid[scratch_slab] = true;
       }
+    }
+    if (e == hipSuccess && !capturing && ctx->overlap && sc) {
+      if (!sc->last_done) PT_HIP(hipEventCreateWithFlags(&sc->last_done, hipEventDisableTiming));
+      PT_HIP(hipEventRecord(sc->last_done, stream));
     }
   } else {
     e = launch_megakernel(p, kind, resident, lds, stats, stream);
@@ -587,6 +606,16 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
       if (ge != hipSuccess) return hip_fail("ptamd_create: gamma table", ge);
     }
   }
+  if (const char* e = std::getenv("PTAMD_OVERLAP")) ctx->overlap = std::atoi(e) != 0; // tuning knob
+  if (ctx->overlap) {
+    // the two internal streams of the launch pipeline, with their hardware queues brought up now (a stream's first
+    // operation costs ~6 ms on this runtime: it would otherwise land in the frame where a host starts to run ahead)
+    for (hipStream_t& is : ctx->internal) {
+      PT_HIP(hipStreamCreateWithFlags(&is, hipStreamNonBlocking));
+      PT_HIP(hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), is));
+      PT_HIP(hipStreamSynchronize(is));
+    }
+  }
   hipDeviceProp_t prop;
   PT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   ctx->n_cus = prop.multiProcessorCount;
@@ -612,8 +641,6 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   }
   if (const char* e = std::getenv("PTAMD_SHORT_RCP")) ctx->short_rcp = std::atoi(e) != 0; // tuning knob
   if (const char* e = std::getenv("PTAMD_POOL_LDS")) ctx->pool_in_lds = std::atoi(e) != 0; // tuning knob
-  if (const char* e = std::getenv("PTAMD_OVERLAP")) ctx->overlap = std::atoi(e) != 0; // tuning knob
-  if (const char* e = std::getenv("PTAMD_POOL_SHARE")) ctx->pool_share = std::atoi(e) != 0; // tuning knob
   if (const char* e = std::getenv("PTAMD_TREELET")) { // tuning knob
     int v = std::atoi(e);
     ctx->treelet_nodes = (uint32_t)(v < 0 ? 0 : (v > 1024 ? 1024 : v));

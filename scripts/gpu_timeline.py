@@ -50,7 +50,7 @@ def main():
     cube = P.cubemap_for_scene(hs)
     rows = tuple(int(v) for v in args.rows.split(":")) if args.rows else None
     ilv = tuple(int(v) for v in args.interleave.split(":")) if args.interleave else None
-    out = {"pool_share": os.environ.get("PTAMD_POOL_SHARE", "1"), "rows": rows, "interleave": ilv, "machine_share": args.share, "launches": []}
+    out = {"tail_handover": os.environ.get("PTAMD_TAIL", "1"), "rows": rows, "interleave": ilv, "machine_share": args.share, "launches": []}
     with P.Context(0) as ctx:
         sid, cid = ctx.upload_scene(hs), ctx.upload_cubemap(cube)
         fr = P.FrameRenderer(ctx, sid, cid, hs.camera_struct(), W, H, rows=rows, band_local=rows is not None, machine_share=args.share, interleave=ilv)
