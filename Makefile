@@ -8,6 +8,10 @@ ARCH     ?= gfx950
 #   shuffles and spills; scalar code is 6.8 % faster (scripts/gpu_flags.sh)
 HIPFLAGS := $(EXTRA_HIPFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -Iinclude -I$(PKG)/host -I$(PKG)/csrc \
             -Wall -Wextra -Wno-unused-parameter
+# identity of the device code: the sources every kernel is compiled from + the flags (profiles/pmc_latest.json carries the id of
+# the build its counters were collected on; bench.py refuses to price a roofline with counters of another build)
+DEVICE_SRCS := $(PKG)/csrc/pt_kernels.hip $(PKG)/csrc/pt_device.h $(PKG)/csrc/pt_launch.h
+BUILD_ID := $(shell (cat $(DEVICE_SRCS); echo "$(HIPFLAGS)") | sha256sum | cut -c1-16)
 LIB      := $(PKG)/libptamd.so
 SRCS     := $(PKG)/csrc/pt_kernels.hip $(PKG)/csrc/ptamd_api.cpp $(PKG)/host/scene_loader.cpp $(PKG)/host/bvh_builder.cpp $(PKG)/host/image_decode.cpp $(PKG)/host/image_png.cpp $(PKG)/host/image_resize.cpp
 HDRS     := include/ptamd.h $(PKG)/host/ptamd_internal.h $(PKG)/csrc/pt_device.h $(PKG)/csrc/pt_launch.h
@@ -19,7 +23,7 @@ lib: $(LIB)
 oracle: $(ORACLE)
 
 $(LIB): $(SRCS) $(HDRS)
-	$(HIPCC) $(HIPFLAGS) -x hip -shared -o $@ $(SRCS)
+	$(HIPCC) $(HIPFLAGS) -DPTAMD_BUILD_ID=\"$(BUILD_ID)\" -x hip -shared -o $@ $(SRCS)
 
 $(ORACLE): oracle/pt_oracle.c oracle/pt_oracle.h
 	gcc -O2 -std=c11 -ffp-contract=off -mfma -fPIC -shared -Wall -Wextra -o $@ oracle/pt_oracle.c -lm -lpthread

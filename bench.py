@@ -71,6 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--atrium", action="store_true",
                     help="configs[3]: generate the seed-fixed Sponza-class atrium (264 832 triangles) as OBJ + MTL + .scene in a "
                          "temporary directory and render that scene (through the same loader as any other asset)")
+    ap.add_argument("--fix-backslashes", action="store_true",
+                    help="load the scene with the MTL's backslash texture paths normalised (indoor.scene then gets its real textures)")
     ap.add_argument("--tessellate", type=int, default=1, help="split every face into n*n (24 -> ~257k tris: round 1's configs[3] stand-in)")
     ap.add_argument("--aperture", type=float, default=None, help="override the camera aperture (configs[4]: 0.113)")
     ap.add_argument("--kernel", choices=["restart", "persistent", "split", "bvh", "blockwise", "brute"], default="restart")
@@ -97,6 +99,8 @@ def parse_args(argv=None):
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="untimed rendering before the W warm-up steps of every leg, so that the timed steps run at the chip's "
                          "steady clocks (0: none)")
+    ap.add_argument("--no-fallback", action="store_true", help="N > 1 started without a launcher: do not retry with the plain configuration when the ranks fail")
+    ap.add_argument("--fallback-run", action="store_true", help=argparse.SUPPRESS)   # set by self_launch for its second attempt
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_latest.json"),
@@ -109,13 +113,32 @@ def parse_args(argv=None):
 def self_launch(args) -> int:
     """`python bench.py --gpus N` with no WORLD_SIZE: run N ranks under torch.distributed.run as a CHILD process (this
     process never touches the GPU, so nothing is exec'ed or forked after HIP initialisation) and relay its output."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.call(cmd, env=env)
+    def child(extra):
+        with socket.socket() as s2:
+            s2.bind(("127.0.0.1", 0))
+            p2 = s2.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(p2), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        return r.returncode, r.stdout
+
+    rc, line = child([])
+    if rc != 0 and not args.no_fallback:
+        # First contact with a multi-GPU node: the default N > 1 configuration (four frames in flight on quarter-GPU
+        # launches, interleaved bands, collectives from several streams) has only ever run on one GPU.  If it fails, ONE
+        # fresh set of ranks runs the plain configuration — one frame at a time, contiguous bands — and says so in its
+        # line ("fallback": true).  This parent never touches the GPU; no rank is re-executed in place.
+        print(f"bench.py: the {args.gpus}-rank run exited with {rc}; starting the plain configuration once", file=sys.stderr, flush=True)
+        if line.strip():
+            print("bench.py: (discarded output of the failed run) " + line.strip()[:2000], file=sys.stderr, flush=True)
+        rc, line = child(["--frames-in-flight", "1", "--interleave", "0", "--fallback-run"])
+    # stdout carries exactly one JSON line, and only that of a run that ended well
+    sys.stdout.write(line if rc == 0 else "")
+    if rc != 0 and line.strip():
+        print("bench.py: (output of the failed run) " + line.strip()[:2000], file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    return rc
 
 
 class _StdoutToStderr:
@@ -276,12 +299,22 @@ class Workload:
                 torch.cuda.synchronize()
         self.barrier()
         dt = time.perf_counter() - t0
+        self.rank_ms = None
         if self.world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            dt = float(t.item())
+            # every rank's own time (the job's is the slowest) and the all-gather on its own
+            mx, mean, every = self.P.rank_times_ms(dt, self.dev)
+            self.rank_ms = {"max": round(mx / steps, 4), "mean": round(mean / steps, 4), "per_rank": [round(v / steps, 4) for v in every]}
+            dt = mx * 1e-3
         step_ms = sum(a.elapsed_time(b) for a, b in evs) / max(steps, 1)
         return dt, step_ms
+
+    def gather_ms(self, reps=20):
+        """One all-gather of the finished bands with nothing else in flight, mean of `reps` (None without a collective)."""
+        bg = self.slots[0][1]
+        if bg is None:
+            return None
+        with _StdoutToStderr():
+            return self.P.time_gather_ms(bg, reps, self.torch.cuda.synchronize)
 
     def trace_stats(self):
         """Exact traversal counts of one frame (instrumented build of the same kernel, untimed)."""
@@ -310,13 +343,14 @@ class Workload:
         self.ctx.close()
 
 
-def load_pmc(path, kernel_name, W, H, spp, B, frames_per_launch, tessellate, scene):
+def load_pmc(path, kernel_name, W, H, spp, B, frames_per_launch, tessellate, scene, build_id):
     """profiles/pmc_latest.json applies only to the workload it was collected on."""
     try:
         with open(path) as f:
             pj = json.load(f)
     except (OSError, ValueError):
         return None
+    pj["stale"] = pj.get("build_id") != build_id   # counters of another build of the device code: not used for the roofline
     ok = (pj.get("kernel") == kernel_name and pj.get("workload") == f"{W}x{H}" and pj.get("spp") == spp
           and pj.get("bounces") == B and pj.get("frames_per_launch") == frames_per_launch and tessellate == 1
           and pj.get("scene", "indoor.scene") == scene)
@@ -358,12 +392,13 @@ def main():
 
     if args.atrium:
         args.scene = atrium_scene()
-    hs = P.HostScene.load(args.scene)
+    hs = P.HostScene.load(args.scene, normalise_backslashes=args.fix_backslashes)
     if args.tessellate > 1:
         hs = P.tessellate(hs, args.tessellate)
     if args.aperture is not None:
         hs.camera["aperture"] = args.aperture
-    cube = P.cubemap_for_scene(hs)
+    # (indoor.scene names a cube cross that does not ship: the 1x1 fallback colour either way, as in the reference)
+    cube = P.cubemap_for_scene(hs, asset_folder=os.path.dirname(os.path.abspath(args.scene)))
     # measured on one rank's share of an 8-way split (scripts/band_proxy.py): 3 / 4 / 5 frames in flight = 0.166 / 0.155 / 0.183 ms
     # whole frame on one GPU, last build of round 2: 2 / 3 / 4 in flight = 9927 / 9930 / 10031 Msamples/s over 60 steps
     # (scripts/gpu_fif.sh) but 9815 / 9660 / 9590 over the 20 steps the driver times: the deeper pipeline drains longer at the
@@ -394,6 +429,7 @@ def main():
                   local_rank, world, rank, gather, rows, interleave)
     proxy = rows is not None or (interleave is not None and world == 1)
     dt, step_ms = wl.run(args.steps, args.warmup, args.settle_ms)
+    gather_ms = wl.gather_ms() if (world > 1 or force_gather) else None
     frames_per_launch = wl.frames_per_launch
     launches_per_step = spp // frames_per_launch
     # one step = launches_per_step megakernel launches (+ the small resolve kernel when batched) back to back on its stream
@@ -407,7 +443,8 @@ def main():
     compulsory_launch = 28 * wl.my_rows * W * frames_per_launch + hs.scene_bytes()
 
     extra = {}
-    is_headline = (W, H, spp, B, args.tessellate, args.aperture, args.atrium, proxy) == (WIDTH, HEIGHT, SPP, BOUNCES, 1, None, False, False)
+    is_headline = (W, H, spp, B, args.tessellate, args.aperture, args.atrium, proxy, args.fix_backslashes, os.path.basename(args.scene)) == \
+                  (WIDTH, HEIGHT, SPP, BOUNCES, 1, None, False, False, False, "indoor.scene")
     if world == 1 and not args.no_extra and not force_gather and not proxy:
         k2 = max(4, args.steps // 2)
         # (a) the same batched launch on one stream: issued back to back, and with the host waiting for every frame (latency)
@@ -460,7 +497,11 @@ def main():
             extra["other_configs"] = others
 
     if rank == 0:
-        pmc = load_pmc(args.pmc_json, args.kernel, W, H, spp, B, frames_per_launch, args.tessellate, os.path.basename(args.scene))
+        build_id = P.native.load().ptamd_build_id().decode()
+        pmc = load_pmc(args.pmc_json, args.kernel, W, H, spp, B, frames_per_launch, args.tessellate, os.path.basename(args.scene), build_id)
+        pmc_stale = bool(pmc is not None and pmc.get("stale"))
+        if pmc_stale:
+            pmc = None   # frac / achieved / traffic stay null: the committed counters belong to another build of the kernels
         valu_per_sample = active_lanes = traffic = None
         if pmc is not None:
             valu_per_sample = pmc.get("valu_insts_per_sample")
@@ -487,6 +528,7 @@ def main():
             "valu_busy_at_measured_clock": None if (pmc is None or not pmc.get("gui_active_cycles_per_launch") or not pmc.get("valu_insts_per_launch"))
             else round(pmc["valu_insts_per_launch"] * VALU_CYCLES * n_slots / (N_SIMDS * pmc["gui_active_cycles_per_launch"]), 4),
             "pmc_source": None if pmc is None else pmc.get("source"),
+            "build_id": build_id, "pmc_stale": pmc_stale,
             "peak_note": f"{N_SIMDS} SIMDs x {CLOCK_GHZ} GHz / {VALU_CYCLES} cycles per wave64 VALU instruction "
                          "(MI355X_MICROARCH.md: v_fma_f32 2 cyc on SIMD-32; 64 lanes x 2 flop x this = the 157.3 TFLOP/s FP32 vector peak)",
             "hbm_peak_gbps": HBM_PEAK_GBPS,
@@ -500,6 +542,15 @@ def main():
             # instrumented build of the same kernel: share of the box-test loop's lane slots that test a box
             "box_loop_lane_utilisation": None if box_iters == 0 else round(stats["nodes_visited"] / (64.0 * box_iters), 4),
         }
+        # SURVEY §8(d)'s per-unit figure, re-homed: the traversal's algorithmic bytes are LDS reads on this scene (36 B per node
+        # visit: 32-byte box + 4-byte link word; 48 B per triangle record), counted exactly by the instrumented build, plus the
+        # 28 B of accumulator / surface traffic per sample; against the aggregate LDS read rate (MI355X_MICROARCH.md: ~150 TB/s for
+        # ds_read_b64/b128 with every CU streaming).  It documents that LDS bandwidth does not bind either.
+        if info["lds_bytes_bvh"] <= 64 * 1024 and stats["samples"]:
+            trav = (stats["nodes_visited"] * 36.0 + stats["tris_tested"] * 48.0) / stats["samples"]
+            lds_gbps = trav * W * (wl.my_rows if proxy else H) * spp * args.steps / dt / 1e9
+            roof["lds"] = {"bound": "lds", "algorithmic_bytes_per_sample": round(trav + 28.0, 1), "traversal_lds_bytes_per_sample": round(trav, 1),
+                           "achieved": round(lds_gbps, 1), "peak": 150000.0, "unit": "GB/s", "frac": round(lds_gbps / 150000.0, 4)}
         cfg_tag = ""
         if is_headline:
             cfg_tag = " (configs[1])" if world == 1 else " (configs[2])"
@@ -528,6 +579,13 @@ def main():
             "roofline": roof,
             "rgba_checksum_rank0_band": checksum,
         }
+        if gather_ms is not None:
+            # the gather is inside ms_per_step (overlapped with the next frames' rendering) and reported on its own
+            out["gather_ms"] = round(gather_ms, 4)
+        if wl.rank_ms is not None:
+            out["per_rank_ms"] = wl.rank_ms          # ms per step on each rank's own clock: max = the job's, max / mean = imbalance
+        if args.fallback_run:
+            out["fallback"] = True
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, cube, W, H, B, args.cpu_seconds)

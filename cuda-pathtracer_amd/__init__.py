@@ -12,7 +12,7 @@ from .scene import (HostScene, cubemap_for_scene, cubemap_from_color, cubemap_fr
                     FACE_DTYPE, MATERIAL_DTYPE, LIGHT_DTYPE, TEXTURE_DTYPE, CAMERA_DTYPE)
 from .render import (Context, FrameRenderer, host_bvh_trace, host_bvh4_trace, interleaved_rows, wang_hash, REFERENCE_BOUNCES,
                      POST_NONE, POST_GRAYSCALE, POST_SEPIA, POST_INVERT)
-from .tiles import row_bands, band_of_rank, BandGather, interleaved_bands
+from .tiles import row_bands, band_of_rank, BandGather, interleaved_bands, rank_times_ms, time_gather_ms
 from .synthetic import tessellate
 from .image import save_ppm, load_ppm, save_png
 from .images import pil_image_loader, ldr_to_float, load_image, load_image8, native_image_loader, resize_float

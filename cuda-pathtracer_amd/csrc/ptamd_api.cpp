@@ -554,7 +554,11 @@ using namespace ptamd;
 extern "C" {
 
 const char* ptamd_get_last_error(void) { return g_last_error.c_str(); }
-const char* ptamd_version(void) { return "ptamd 0.1 (gfx950)"; }
+#ifndef PTAMD_BUILD_ID
+#define PTAMD_BUILD_ID "unknown"
+#endif
+const char* ptamd_version(void) { return "ptamd 0.3 (gfx950) device code " PTAMD_BUILD_ID; }
+const char* ptamd_build_id(void) { return PTAMD_BUILD_ID; }
 
 uint32_t ptamd_interleaved_rows(uint32_t height, uint32_t ranks, uint32_t rank, uint32_t band_rows)
 {

@@ -101,6 +101,7 @@ LOAD_FIX_BACKSLASHES, LOAD_NO_IMAGES = 1, 2   # ptamd_host_scene_load flags
 SIGNATURES = {
     "ptamd_get_last_error": (C.c_char_p, []),
     "ptamd_version": (C.c_char_p, []),
+    "ptamd_build_id": (C.c_char_p, []),
     "ptamd_host_scene_load": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "ptamd_host_scene_load_ex": (C.c_int, [C.c_char_p, C.c_uint32, IMAGE_LOAD_FN, IMAGE_FREE_FN, C.c_void_p,
                                             C.POINTER(C.c_void_p)]),

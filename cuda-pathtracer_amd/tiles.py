@@ -96,3 +96,36 @@ class BandGather:
             return self.recv.index_select(0, self.index)
         parts = [self.recv[r * self.max_rows: r * self.max_rows + (e - b)] for r, (b, e) in enumerate(self.bands)]
         return torch.cat(parts, dim=0)
+
+
+def rank_times_ms(seconds: float, device, group=None):
+    """Every rank's own time for the timed region, gathered on all ranks: (max, mean, list) in milliseconds.  bench.py
+    reports max and mean next to the job's time (per-rank times; the gap between them is load imbalance)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([seconds * 1e3], dtype=torch.float64, device=device)
+    every = torch.zeros(world, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(every, mine, group=group)
+    vals = [float(v) for v in every.tolist()]
+    return max(vals), sum(vals) / len(vals), vals
+
+
+def time_gather_ms(bg: "BandGather", reps: int, synchronize, group=None) -> float:
+    """Mean time of ONE all-gather of the RGBA8 bands with nothing else in flight (the gather reported
+    separately): `reps` gathers between two barriers, the slowest rank's time.  synchronize(): waits for the device
+    (torch.cuda.synchronize on GPUs, a no-op for gloo)."""
+    import time
+    import torch
+    import torch.distributed as dist
+    bg.gather(bg.send_rows(), group=group)        # communicator / buffers warm
+    synchronize()
+    dist.barrier(group=group)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        bg.gather(bg.send_rows(), group=group)
+    synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=bg.send.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item()) / max(reps, 1) * 1e3

@@ -23,6 +23,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,20 +44,55 @@ struct Options {
 
 std::atomic<int> g_failed{0};
 
+// A rank that fails must not leave its peers waiting inside a collective for ever: it raises g_failed and aborts every
+// communicator (ncclCommAbort may be called from any thread and makes pending and later operations on it return), and the
+// ranks also meet at host-side rendezvous points — before the first collective and after each timed phase — where a
+// raised flag sends all of them home.
+std::vector<ncclComm_t>* g_comms = nullptr;
+std::once_flag g_abort_once;
+void fail_all()
+{
+  g_failed = 1;
+  std::call_once(g_abort_once, [] { if (g_comms) for (ncclComm_t c : *g_comms) if (c) (void)ncclCommAbort(c); });
+}
+
+class Rendezvous {
+ public:
+  explicit Rendezvous(int n) : n_(n) {}
+  // returns false when any rank has failed (every rank then sees false at the same point)
+  bool meet()
+  {
+    std::unique_lock<std::mutex> lk(m_);
+    const unsigned long gen = gen_;
+    if (++count_ == n_) { count_ = 0; ++gen_; verdict_ = g_failed.load() == 0; cv_.notify_all(); }
+    else cv_.wait(lk, [&] { return gen_ != gen; });
+    return verdict_;
+  }
+  // a rank that returns early still has to be counted at the points its peers will reach
+  void leave() { std::unique_lock<std::mutex> lk(m_); --n_; if (n_ > 0 && count_ == n_) { count_ = 0; ++gen_; verdict_ = false; cv_.notify_all(); } }
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  int n_, count_ = 0;
+  unsigned long gen_ = 0;
+  bool verdict_ = true;
+};
+Rendezvous* g_meet = nullptr;
+
 #define PT_OK(call)                                                                                              \
   do {                                                                                                           \
     int rc_ = (call);                                                                                            \
-    if (rc_ != PTAMD_OK) { std::fprintf(stderr, "[rank %d] %s failed (%d): %s\n", rank, #call, rc_, ptamd_get_last_error()); g_failed = 1; return; } \
+    if (rc_ != PTAMD_OK) { std::fprintf(stderr, "[rank %d] %s failed (%d): %s\n", rank, #call, rc_, ptamd_get_last_error()); fail_all(); g_meet->leave(); return; } \
   } while (0)
 #define HIP_OK(call)                                                                                             \
   do {                                                                                                           \
     hipError_t e_ = (call);                                                                                      \
-    if (e_ != hipSuccess) { std::fprintf(stderr, "[rank %d] %s: %s\n", rank, #call, hipGetErrorString(e_)); g_failed = 1; return; } \
+    if (e_ != hipSuccess) { std::fprintf(stderr, "[rank %d] %s: %s\n", rank, #call, hipGetErrorString(e_)); fail_all(); g_meet->leave(); return; } \
   } while (0)
 #define NCCL_OK(call)                                                                                            \
   do {                                                                                                           \
     ncclResult_t r_ = (call);                                                                                    \
-    if (r_ != ncclSuccess) { std::fprintf(stderr, "[rank %d] %s: %s\n", rank, #call, ncclGetErrorString(r_)); g_failed = 1; return; } \
+    if (r_ != ncclSuccess) { std::fprintf(stderr, "[rank %d] %s: %s\n", rank, #call, ncclGetErrorString(r_)); fail_all(); g_meet->leave(); return; } \
   } while (0)
 
 // Contiguous row bands, remainders to the last ranks (cuda_pathtracer_amd/tiles.py: row_bands).
@@ -130,13 +167,17 @@ void rank_main(int rank, int world, Shared* sh)
     if (ptamd_raytrace_ex(ctx, &l) != PTAMD_OK) return false;
     return ncclAllGather(surface, gathered, band_bytes, ncclUint8, sh->comms[rank], stream) == ncclSuccess;
   };
+  // every rank has its context, scene and buffers: only now may anyone enter a collective
+  if (!g_meet->meet()) return;
   for (int i = 0; i < 3; ++i)
-    if (!frame()) { std::fprintf(stderr, "[rank %d] warm-up frame failed: %s\n", rank, ptamd_get_last_error()); g_failed = 1; return; }
+    if (!frame()) { std::fprintf(stderr, "[rank %d] warm-up frame failed: %s\n", rank, ptamd_get_last_error()); fail_all(); g_meet->leave(); return; }
   HIP_OK(hipStreamSynchronize(stream));
+  if (!g_meet->meet()) return;
   const auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < o.frames; ++i)
-    if (!frame()) { std::fprintf(stderr, "[rank %d] frame failed: %s\n", rank, ptamd_get_last_error()); g_failed = 1; return; }
+    if (!frame()) { std::fprintf(stderr, "[rank %d] frame failed: %s\n", rank, ptamd_get_last_error()); fail_all(); g_meet->leave(); return; }
   HIP_OK(hipStreamSynchronize(stream));
+  if (!g_meet->meet()) return;
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / o.frames;
 
   if (rank == 0) {
@@ -243,10 +284,13 @@ int main(int argc, char** argv)
   std::vector<int> devs((size_t)world);
   for (int r = 0; r < world; ++r) devs[(size_t)r] = r;
   if (ncclCommInitAll(sh.comms.data(), world, devs.data()) != ncclSuccess) { std::fprintf(stderr, "ncclCommInitAll failed\n"); return 1; }
+  Rendezvous meet(world);
+  g_meet = &meet;
+  g_comms = &sh.comms;
   std::vector<std::thread> threads;
   for (int r = 0; r < world; ++r) threads.emplace_back(rank_main, r, world, &sh);
   for (auto& t : threads) t.join();
-  for (auto c : sh.comms) ncclCommDestroy(c);
+  if (!g_failed) for (auto c : sh.comms) ncclCommDestroy(c);   // (aborted communicators are gone already)
   ptamd_host_scene_free(hs);
   if (g_failed) return 1;
 

@@ -105,6 +105,10 @@ typedef struct {
 
 const char* ptamd_get_last_error(void);
 const char* ptamd_version(void);
+/* 16 hex digits: sha256 of the device sources (csrc/pt_kernels.hip, pt_device.h, pt_launch.h) and the compiler flags this
+ * library's code object was built from.  Profiles carry it (profiles/pmc_latest.json), so that counters of one build are
+ * never used to price another. */
+const char* ptamd_build_id(void);
 
 /* ---- host-side scene loader (replaces scene::Scene::upload's parsing half,
  *      scene.cpp:86-170,202-262,304-358 and material_loader.cpp:153-401) --------------- */

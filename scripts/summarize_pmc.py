@@ -18,6 +18,7 @@ ap.add_argument("--sequential", action="store_true")
 ap.add_argument("--atrium", action="store_true")
 ap.add_argument("--scene", default="indoor.scene")
 ap.add_argument("--frames-in-flight", type=int, default=0)
+ap.add_argument("--fix-backslashes", action="store_true")
 bargs, _ = ap.parse_known_args(sys.argv[4:])
 
 acc = {}
@@ -31,6 +32,8 @@ for f in glob.glob(os.path.join(out_dir, "pass*", "**", "*counter_collection.csv
             targs = nm.split("<", 1)[1].split(">", 1)[0].split(",") if "<" in nm else []
             bools = [t for t in targs if t in ("true", "false")]
             if len(bools) >= 2 and bools[1] == "true":      # <.., LDS_RESIDENT, STATS, ..>: skip instrumented launches
+                continue
+            if "pt_megakernel_restart" in nm and len(targs) >= 2 and targs[1] != "0":   # <LDS_RESIDENT, VARIANT>: 0 = the shipped kernel
                 continue
             want = {"bvh": "pt_megakernel<", "brute": "pt_megakernel<", "persistent": "pt_megakernel_persistent<",
                     "blockwise": "pt_megakernel_blockwise<", "split": "pt_megakernel_split<", "restart": "pt_megakernel_restart<"}.get(kernel)
@@ -67,7 +70,10 @@ res["_kernel"] = kernel
 print(json.dumps(res, indent=1))
 
 fetch_kb, write_kb = res.get("FETCH_SIZE"), res.get("WRITE_SIZE")
-rec = {"kernel": kernel, "scene": "atrium.scene" if bargs.atrium else os.path.basename(bargs.scene), "workload": f"{bargs.width}x{bargs.height}", "spp": bargs.spp, "bounces": bargs.bounces,
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+os.environ.setdefault("PTAMD_NO_TORCH_PRELOAD", "1")
+from cuda_pathtracer_amd import native as _native   # the id of the library the passes ran with (same work tree)
+rec = {"build_id": _native.load().ptamd_build_id().decode(), "kernel": kernel, "scene": "atrium.scene" if bargs.atrium else os.path.basename(bargs.scene) + (" (textured)" if bargs.fix_backslashes else ""), "workload": f"{bargs.width}x{bargs.height}", "spp": bargs.spp, "bounces": bargs.bounces,
        "frames_per_launch": fpl, "samples_per_launch": samples,
        "valu_insts_per_launch": res.get("SQ_INSTS_VALU"), "valu_insts_per_sample": d.get("valu_insts_per_sample"),
        "active_lanes": d.get("valu_active_lanes_per_inst(of 64)"),

@@ -92,6 +92,40 @@ def test_two_rank_split_and_gather_equals_single_rank(P, O, indoor, tmp_path):
     np.testing.assert_array_equal(frame, want)
 
 
+REPORT_WORKER = textwrap.dedent("""
+    import os, sys, json, time
+    sys.path[:0] = [{root!r}]
+    import torch, torch.distributed as dist
+    import cuda_pathtracer_amd as P
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bg = P.BandGather(64, 32, world, rank, torch.device("cpu"), interleave=8)
+    bg.send_rows().fill_(rank + 1)
+    g_ms = P.time_gather_ms(bg, 5, lambda: None)
+    mx, mean, every = P.rank_times_ms(0.010 * (rank + 1), torch.device("cpu"))
+    if rank == 0:
+        frame = bg.assemble()
+        json.dump({{"gather_ms": g_ms, "max": mx, "mean": mean, "every": every,
+                    "rows_ok": bool((frame[0:8] == 1).all() and (frame[8:16] == 2).all() and (frame[16:24] == 1).all())}}, open({out!r}, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_per_rank_times_and_separate_gather_time(tmp_path):
+    """The two N > 1 reporting helpers bench.py uses (per_rank_ms, gather_ms) on a world-size-2 gloo job."""
+    import json
+    out = str(tmp_path / "report.json")
+    script = tmp_path / "report_worker.py"
+    script.write_text(REPORT_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29523", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29523", str(script)], env=env, cwd=ROOT, timeout=600)
+    r = json.load(open(out))
+    assert r["rows_ok"] and r["gather_ms"] > 0.0
+    assert r["every"] == pytest.approx([10.0, 20.0]) and r["max"] == pytest.approx(20.0) and r["mean"] == pytest.approx(15.0)
+
+
 def test_bench_gpus_n_starts_its_own_ranks():
     """`python bench.py --gpus 2` (no WORLD_SIZE: how a driver without a launcher calls it) must start two ranks by itself.
     On a GPU-less box the ranks then stop at "needs a GPU" — not at a refusal to start."""
@@ -104,6 +138,8 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert r.returncode != 0
     # the ranks got as far as the device check (the launcher may stop the second one as soon as the first has failed)
     assert r.stderr.count("bench.py needs a GPU") >= 1, r.stderr[-2000:]
+    # ... and the plain configuration was tried once after the default one had failed (and failed for the same reason here)
+    assert r.stderr.count("starting the plain configuration once") == 1
     assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr        # ... under the launcher bench.py started
     assert "must be launched with" not in r.stderr and r.stdout.strip() == ""
 

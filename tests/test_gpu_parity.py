@@ -583,6 +583,79 @@ def test_far_camera_keeps_bvh_exact(P, O, gpu_ctx):
             assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref, f"camera at {dist:g}/batched")
 
 
+def test_far_camera_with_interleaved_bands_and_batches(P, O, gpu_ctx):
+    """a camera beyond the box margins' reach used to send interleaved-band launches to the one-thread-per-pixel
+    kernel, which renders the WHOLE frame into band-local buffers.  Such launches now stay in the restart kernel (its
+    every-triangle instantiation): interleaved bands, batched or not, put back in frame order equal the full-frame render
+    and the oracle."""
+    if os.environ.get("PTAMD_DEFAULT_KERNEL", "6") != "6":
+        pytest.skip("interleaved bands need the restart kernel behind PTAMD_KERNEL_AUTO")
+    import torch
+    rng = np.random.default_rng(5)
+    n = 200
+    c = rng.uniform(-1.0, 1.0, size=(n, 1, 3))
+    tris = (c + rng.normal(scale=0.08, size=(n, 3, 3)) * np.float32([1.0, 1.0, 0.002])).astype(np.float32)
+    cube = synthetic_cubemap(rng, 2)
+    dist, fov = 1.0e5, 0.00004
+    hs = make_scene(P, tris, lights=[((0.0, 0.5, 2.0), (1.0, 0.9, 0.8), 4.0, 0.3)],
+                    camera=dict(position=(0.0, 0.0, dist), dir=(0.0, 0.0, -1.0), fov_x=fov, aperture=0.0, focus_dist=dist))
+    W, H, spp, B = 72, 50, 2, 3
+    ref_acc, ref_rgba = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), W, H, spp=spp, bounces=B)
+    assert (ref_acc > 0).any()
+    ids = (gpu_ctx.upload_scene(hs), gpu_ctx.upload_cubemap(cube))
+    for kernel in (P.KERNEL_AUTO, P.KERNEL_BVH_RESTART):
+        acc, rgba = gpu_render(P, gpu_ctx, hs, cube, W, H, spp, B, kernel, ids=ids)
+        assert_same(acc, rgba, ref_acc, ref_rgba, f"far camera, kernel {kernel}")
+    world, rank_rows = 4, 8
+    for batched in (False, True):
+        rgba = np.zeros_like(ref_rgba)
+        acc = np.zeros_like(ref_acc)
+        for rank in range(world):
+            fr = P.FrameRenderer(gpu_ctx, *ids, hs.camera_struct(), W, H, interleave=(world, rank, rank_rows))
+            fr.render(spp=spp, bounces=B, batched=batched and batched_ok())
+            torch.cuda.synchronize()
+            s, a = fr.surface.cpu().numpy(), fr.accum.cpu().numpy()
+            local = 0
+            for b, e in P.interleaved_bands(H, world, rank, rank_rows):
+                rgba[b:e] = s[local:local + (e - b)]
+                acc[H - e:H - b] = a[s.shape[0] - (local + (e - b)):s.shape[0] - local]
+                local += e - b
+        assert_same(acc, rgba, ref_acc, ref_rgba, f"far camera, interleaved bands, batched={batched}")
+
+
+def test_back_to_back_launches_on_one_stream(P, gpu_ctx, indoor):
+    """A host that issues launches without waiting for them (the reference's render loop, gpu_processor.cpp:365-386) has
+    consecutive launches of a stream pipelined by the library: half-GPU launches whose megakernels run on internal
+    streams, resolve passes in order on the caller's.  Same accumulator and surface, bit for bit, as when the host waits
+    for every launch — single-frame and batched launches, two renderers taking turns on one stream, and the default
+    stream as well as a created one."""
+    import torch
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    W, H, B = 1920, 1080, 4
+
+    def run(stream, wait, batched):
+        frs = [P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H) for _ in range(2)]
+        torch.cuda.synchronize()   # (the buffers were zeroed on the default stream)
+        frame = 1
+        for step in range(6):
+            fr = frs[step % 2]
+            n = 3 if batched else 1
+            fr.render(spp=n, bounces=B, kernel=P.KERNEL_AUTO, stream=stream, first_frame=frame, batched=batched and batched_ok())
+            frame += n
+            if wait:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return [(f.accum.cpu().numpy(), f.surface.cpu().numpy()) for f in frs]
+
+    for batched in (False, True):
+        want = run(None, True, batched)
+        for stream in (None, torch.cuda.Stream()):
+            got = run(stream, False, batched)
+            for (a, s), (wa, ws) in zip(got, want):
+                assert_same(a, s, wa, ws, f"back to back, batched={batched}, stream={'default' if stream is None else 'created'}")
+
+
 def test_crate_land_with_real_textures_and_cubemap(P, O, gpu_ctx):
     """The reference scene that exercises sampleTexture on 1024^2 RGBA textures, normal mapping and
     a bilinear 1024^2 cubemap, decoded by the built-in decoder (== the reference's stb_image, test_ref_thirdparty)."""
