@@ -1233,6 +1233,8 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
     }
 #endif
   }
+  // (references and order words are needed last, but fetched with the boxes: one round trip per visit)
+  asm volatile("" : "+v"(refs.x), "+v"(refs.y), "+v"(refs.z), "+v"(refs.w), "+v"(ord.x), "+v"(ord.y), "+v"(ord.z), "+v"(ord.w));
   float tn[4];
   uint32_t hit = 0;
 #define PT_CHILD(c, X)                                                                                                   \
@@ -1270,14 +1272,105 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
   return next;
 }
 
+// ---------------------------------------------------------------- eight-wide walk over quantised nodes (round 3)
+//
+// The four-wide walk of round 2 ran at 72 % of the request rate the L2 / Infinity-Cache path sustains for random 128-byte
+// records (profiles/r02_gather_ubench.txt), so the lever is requests per ray.  A node of Bvh::nodes8 (host/ptamd_internal.h)
+// still is ONE 128-byte line but holds EIGHT child boxes: a float origin, one power-of-two scale per axis and 8-bit planes,
+// rounded outward.  15.4 -> 9.3 node visits per ray on the atrium, and the 64 KB of LDS that held the top 512 four-wide nodes
+// (2 048 boxes) now hold 4 096 boxes: two thirds of all visits stay in the CU.  Per node and axis the ray's slab coefficients
+// are folded into the decode:  t = plane * (scale / d) + (origin - o) / d  — one v_cvt_f32_ubyte and one fma per plane.
+// The ray's octant comes from the SIGN BITS of its direction (so that -0.0 agrees with the sign of its stand-in reciprocal);
+// it selects the entry / exit plane arrays (no min / max per axis) and the visiting order: children sit in slots by direction
+// (bvh_builder.cpp), ascending (slot ^ octant) is front to back.  far[c] = the slots a ray of this octant reaches AFTER slot c
+// (one byte per slot, two dwords per ray, from KParams::far_table): a hit child's stack position is one popcount.
+#ifndef PT_WIDE8
+#define PT_WIDE8 0   /* 1: the eight-wide quantised nodes (A/B builds; the host side follows the same macro) */
+#endif
+
+struct Walk8 {
+  uint32_t oct;   // bit a: the direction's sign bit along axis a
+  uint2 far;      // byte c: slots visited after slot c
+};
+
+PT_DEV Walk8 walk8_init(const KParams& p, f3 d)
+{
+  Walk8 x;
+  x.oct = (f_as_u(d.x) >> 31) | ((f_as_u(d.y) >> 31) << 1) | ((f_as_u(d.z) >> 31) << 2);
+  // per-lane read of the 64-byte table in the kernel-argument segment (one cached load per walk)
+  typedef const __attribute__((address_space(4))) uint32_t* ConstU;
+  const ConstU tbl = (ConstU)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(KParams, far_table));
+  x.far = make_uint2(tbl[2u * x.oct], tbl[2u * x.oct + 1u]);
+  return x;
+}
+
+// Visits interior node `cur`: tests its eight child boxes, stacks the hit ones, returns the nearest (or pops).
+template <bool STATS>
+PT_DEV uint32_t walk8_visit(const float4* nodes8, const Stack4& stk, const Walk& w, const Walk8& x, uint32_t cur, uint32_t& sp)
+{
+  uint4 hd, ra, rb, pa, pb, pc;
+  if (cur < stk.top_n) {
+    const uint4* q = reinterpret_cast<const uint4*>(stk.top) + cur * 8u;
+    hd = q[0]; ra = q[1]; rb = q[2]; pa = q[3]; pb = q[4]; pc = q[5];
+  } else {
+    const uint4* q = reinterpret_cast<const uint4*>(nodes8) + (size_t)cur * 8u;
+    hd = q[0]; ra = q[1]; rb = q[2]; pa = q[3]; pb = q[4]; pc = q[5];
+  }
+  // (the references are needed last, but fetched now: the compiler would otherwise load them after the box tests — a second
+  // round trip per visit)
+  asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w));
+  // planes: pa = lo.x[8] lo.y[8], pb = lo.z[8] hi.x[8], pc = hi.y[8] hi.z[8]; the ray enters through `en`, leaves through `ex`
+  const bool nx = (x.oct & 1u) != 0u, ny = (x.oct & 2u) != 0u, nz = (x.oct & 4u) != 0u;
+  const uint32_t enx0 = nx ? pb.z : pa.x, enx1 = nx ? pb.w : pa.y, exx0 = nx ? pa.x : pb.z, exx1 = nx ? pa.y : pb.w;
+  const uint32_t eny0 = ny ? pc.x : pa.z, eny1 = ny ? pc.y : pa.w, exy0 = ny ? pa.z : pc.x, exy1 = ny ? pa.w : pc.y;
+  const uint32_t enz0 = nz ? pc.z : pb.x, enz1 = nz ? pc.w : pb.y, exz0 = nz ? pb.x : pc.z, exz1 = nz ? pb.y : pc.w;
+  const float ax = u_as_f((hd.w & 0xFFu) << 23) * w.inv.x, ay = u_as_f(((hd.w >> 8) & 0xFFu) << 23) * w.inv.y,
+              az = u_as_f(((hd.w >> 16) & 0xFFu) << 23) * w.inv.z;
+  const float bx = __builtin_fmaf(u_as_f(hd.x), w.inv.x, w.noi.x), by = __builtin_fmaf(u_as_f(hd.y), w.inv.y, w.noi.y),
+              bz = __builtin_fmaf(u_as_f(hd.z), w.inv.z, w.noi.z);
+  float tn[8];
+  uint32_t hit = 0;
+#define PT_CHILD8(c, W0, SH)                                                                                              \
+  {                                                                                                                      \
+    const float tnx = __builtin_fmaf((float)((enx##W0 >> SH) & 0xFFu), ax, bx), tfx = __builtin_fmaf((float)((exx##W0 >> SH) & 0xFFu), ax, bx); \
+    const float tny = __builtin_fmaf((float)((eny##W0 >> SH) & 0xFFu), ay, by), tfy = __builtin_fmaf((float)((exy##W0 >> SH) & 0xFFu), ay, by); \
+    const float tnz = __builtin_fmaf((float)((enz##W0 >> SH) & 0xFFu), az, bz), tfz = __builtin_fmaf((float)((exz##W0 >> SH) & 0xFFu), az, bz); \
+    tn[c] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), 0.0f);                                      \
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), w.best.t);                         \
+    if (tn[c] <= tf) hit |= 1u << c;                                                                                     \
+  }
+  PT_CHILD8(0, 0, 0) PT_CHILD8(1, 0, 8) PT_CHILD8(2, 0, 16) PT_CHILD8(3, 0, 24)
+  PT_CHILD8(4, 1, 0) PT_CHILD8(5, 1, 8) PT_CHILD8(6, 1, 16) PT_CHILD8(7, 1, 24)
+#undef PT_CHILD8
+  if (hit == 0u) return stack4_pop(stk, sp, w.best.t);
+  const uint32_t nhit = (uint32_t)__builtin_popcount(hit);
+  const uint32_t ref[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+  uint32_t next = PT_NONE;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if ((hit >> c) & 1u) {
+      // hit children farther than c go deeper; the nearest is visited next without a round trip through the stack
+      const uint32_t farther = ((c < 4 ? x.far.x : x.far.y) >> (8 * (c & 3))) & 0xFFu;
+      const uint32_t rank = (uint32_t)__builtin_popcount(hit & farther);
+      if (rank + 1u == nhit) next = ref[c];
+      else stack4_write(stk, sp + rank, ref[c], tn[c]);
+    }
+  }
+  sp += nhit - 1u;
+  return next;
+}
+
 // One round of the wide walk for the lanes that call it (see traverse_round): cur == PT_NONE on return: finished.
 template <bool STATS>
-PT_DEV void traverse_round4(const float4* nodes4, const float4* tris, const Stack4& stk, f3 o, f3 d, Best& best, uint32_t& cur,
+PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4* tris, const Stack4& stk, f3 o, f3 d, Best& best, uint32_t& cur,
                             uint32_t& sp, uint32_t round_min, uint32_t round_div, uint32_t walk_min, bool small_det, Counters& cnt)
 {
   Walk w;
   walk_init(w, o, d, 1u);
   w.best = best;
+#if PT_WIDE8
+  const Walk8 x8 = walk8_init(p, d);
+#endif
   const uint32_t n_start = (uint32_t)__popcll(__ballot(cur != PT_NONE));
   uint32_t t_eff = (n_start + round_div - 1u) / round_div;
   if (t_eff > round_min) t_eff = round_min;
@@ -1293,7 +1386,11 @@ PT_DEV void traverse_round4(const float4* nodes4, const float4* tris, const Stac
           cnt.nodes++;
           if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) cnt.wave_node_iters++;
         }
+#if PT_WIDE8
+        cur = walk8_visit<STATS>(nodes4, stk, w, x8, cur, sp);
+#else
         cur = walk4_visit<STATS>(nodes4, stk, w, cur, sp);
+#endif
       }
       if (walkers < walk_min) break;
     }
@@ -1495,7 +1592,7 @@ pt_megakernel_restart(const KParams p)
         if (STATS) cnt.tris += p.n_bvh_tris;
         node = PT_END;
       } else if (WIDE) {
-        traverse_round4<STATS>(p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, p.small_det != 0u, cnt);
+        traverse_round4<STATS>(p, p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, p.small_det != 0u, cnt);
         node = cur == PT_NONE ? PT_END : 0u;
       } else {
         traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.walk_min, p.small_det != 0u, cnt);
@@ -1993,7 +2090,7 @@ __global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(const KParams p,
   Best best;
   best.t = PT_MAX_DIST; best.u = best.v = 0.f; best.idx = PT_END;
   uint32_t cur = (live && p.n_nodes4) ? 0u : PT_NONE, sp = 0u;
-  if (live) traverse_round4<false>(p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, p.small_det != 0u, cnt);
+  if (live) traverse_round4<false>(p, p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, p.small_det != 0u, cnt);
   if (!live) return;
   Nearest nr;
   nr.t = best.t; nr.u = best.u; nr.v = best.v; nr.idx = best.idx;

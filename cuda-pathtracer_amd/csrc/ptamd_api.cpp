@@ -27,7 +27,7 @@ namespace {
 
 struct DeviceScene {
   float4* nodes = nullptr;
-  float4* nodes4 = nullptr;   // the four-wide form of the same tree (8 float4 per node)
+  float4* nodes4 = nullptr;   // the wide form of the same tree (8 float4 per node: eight-wide quantised, or four-wide in PT_WIDE8=0 builds)
   float4* tris_bvh = nullptr;
   float4* tris_brute = nullptr;
   float4* shade = nullptr;
@@ -128,7 +128,7 @@ float frame_nb_inverse(float c)
   return 1.0f / c;
 }
 constexpr uint32_t kCompactMaxNodes = 896;   // 896 * 32 B = 28 KB of boxes below 0x8000 with 4 KB to spare for static LDS
-constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit)
+constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit); a 128-byte stride (one line per record) measured -0.7 % on the atrium
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
 constexpr uint32_t kMaxLeaf = 3;   // 3 beats 4 by 1.2 % now that a box test costs a third of a triangle test (scripts/gpu_knobs.sh)
 constexpr uint32_t kTicketRing = 1024;
@@ -169,6 +169,24 @@ void free_scene(DeviceScene& s)
   void* ptrs[] = { s.nodes, s.nodes4, s.tris_bvh, s.tris_brute, s.shade, s.materials, s.lights, s.textures, s.texels };
   for (void* q : ptrs) (void)hipFree(q);
   s = DeviceScene();
+}
+
+#ifndef PT_WIDE8
+#define PT_WIDE8 0   /* same macro as pt_kernels.hip: 1 = the eight-wide quantised nodes, 0 = the four-wide float nodes */
+#endif
+// KParams::far_table: children sit in slots by direction and a ray of octant o visits them in ascending (slot ^ o) order;
+// byte c of the entry of octant o = the slots visited AFTER slot c
+void fill_far_table(uint32_t t[16])
+{
+  for (uint32_t o = 0; o < 8; ++o) {
+    uint64_t e = 0;
+    for (uint32_t c = 0; c < 8; ++c) {
+      uint32_t m = 0;
+      for (uint32_t d = 0; d < 8; ++d) if ((d ^ o) > (c ^ o)) m |= 1u << d;
+      e |= (uint64_t)m << (8 * c);
+    }
+    t[2 * o] = (uint32_t)e; t[2 * o + 1] = (uint32_t)(e >> 32);
+  }
 }
 
 void free_scratch(ptamd_context::SampleScratch& c)
@@ -241,6 +259,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   p.gamma_table = ctx->d_gamma;
   p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
   p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4;
+  fill_far_table(p.far_table);
   // finite edges of at most 2e8 per axis and unit directions: det = e1 . (dir x e2) is far below 2^125 (or NaN, which
   // both forms of the reciprocal pass on)
   p.small_det = ctx->short_rcp && s.all_finite && s.extent <= 1.0e8f ? 1u : 0u;
@@ -402,7 +421,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     // ([entry][lane], 512 bytes per entry and wave), the rest in a global slab.
     size_t launch_lds = lds;
     if (restart && !resident) {
-      const uint32_t need = 3u * s.depth4 + 1u;
+      const uint32_t need = (PT_WIDE8 ? 7u : 3u) * s.depth4 + 1u;   // a visit stacks all hit children but the nearest
       const uint32_t waves = restart_threads(false) / 64u;
       const uint32_t share = 160u * 1024u / restart_wide_blocks_per_cu() - 256u;   // LDS bytes of one resident workgroup
       // the top of the tree (breadth-first numbering: nodes 0..340 are its first five levels when full) goes to LDS too:
@@ -770,14 +789,15 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   DeviceScene d;
   d.n_faces = sc->n_faces; d.n_lights = sc->n_lights; d.n_nodes = bvh.n_nodes; d.n_bvh_tris = bvh.n_tris;
   d.extent = bvh.extent; d.all_finite = bvh.all_finite; d.margin_floor = bvh.margin_floor;
-  d.n_nodes4 = bvh.n_nodes4; d.depth4 = bvh.depth4;
+  // (d.nodes4 / n_nodes4 / depth4: the wide form the kernels walk — eight-wide unless built with PT_WIDE8=0)
+  d.n_nodes4 = PT_WIDE8 ? bvh.n_nodes8 : bvh.n_nodes4; d.depth4 = PT_WIDE8 ? bvh.depth8 : bvh.depth4;
   d.n_materials = sc->n_materials; d.n_textures = sc->n_textures;
   // device copy of the lights: the radius only ever enters as radius * radius (intersection.cuh:147) — the same binary32
   // product whoever forms it — so the table carries the square in its place and every sphere test saves the multiply
   std::vector<ptamd_light> dev_lights(sc->lights, sc->lights + sc->n_lights);
   for (ptamd_light& dl : dev_lights) dl.radius = dl.radius * dl.radius;
   if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
-      (rc = upload(d.nodes4, bvh.nodes4.data(), bvh.nodes4.size() * 4)) ||
+      (rc = PT_WIDE8 ? upload(d.nodes4, bvh.nodes8.data(), bvh.nodes8.size() * 4) : upload(d.nodes4, bvh.nodes4.data(), bvh.nodes4.size() * 4)) ||
       (rc = upload(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4)) ||
       (rc = upload(d.tris_brute, brute.data(), brute.size() * 4)) ||
       (rc = upload(d.shade, shade.data(), shade.size() * 4)) ||
@@ -791,7 +811,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   d.info.n_faces = sc->n_faces; d.info.n_lights = sc->n_lights; d.info.n_nodes = bvh.n_nodes;
   d.info.n_leaves = bvh.n_leaves; d.info.max_leaf_size = bvh.max_leaf; d.info.depth = bvh.depth;
   d.info.node_bytes = 64; d.info.tri_bytes = 48;
-  d.info.n_nodes4 = bvh.n_nodes4; d.info.depth4 = bvh.depth4;
+  d.info.n_nodes4 = d.n_nodes4; d.info.depth4 = d.depth4;
   d.info.lds_bytes_bvh = bvh.n_nodes * 64u + bvh.n_tris * 48u;
   d.info.lds_bytes_brute = sc->n_faces * 48u;
   ctx->scenes.push_back(d);
@@ -966,8 +986,9 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   p.nodes = s.nodes; p.tris_bvh = s.tris_bvh; p.tris_brute = s.tris_brute; p.lights = s.lights;
   p.n_faces = s.n_faces; p.n_lights = s.n_lights; p.n_nodes = s.n_nodes; p.n_bvh_tris = s.n_bvh_tris;
   p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4;
+  fill_far_table(p.far_table);
   p.small_det = 0u;                           // caller-supplied directions need not be unit vectors
-  p.stack_lds_entries = 3u * s.depth4 + 1u;   // PTAMD_KERNEL_BVH_RESTART: the four-wide walk, whole stack in LDS
+  p.stack_lds_entries = (PT_WIDE8 ? 7u : 3u) * s.depth4 + 1u;   // PTAMD_KERNEL_BVH_RESTART: the wide walk, whole stack in LDS
   float* d_rays = nullptr;
   int4* d_out = nullptr;
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));

@@ -53,6 +53,7 @@ struct BuildNode {
 constexpr float kTravCost = 1.0f;
 float g_isect_cost = 1.6f; // SAH cost of one triangle test relative to one box test (build_bvh may override)
 constexpr int kBins = 32;
+uint32_t g_sweep_limit = 1u << 30;   // nodes with more primitives than this are split by binning (build_bvh may override)
 
 struct Builder {
   std::vector<Prim> prims;
@@ -87,7 +88,7 @@ struct Builder {
     bool best_binned = false;
     const float inv_area = 1.0f / std::max(box.half_area(), 1e-30f);
 
-    if (count <= 2048) {
+    if (count <= g_sweep_limit) {
       std::vector<float> right_area(count);
       for (int a = 0; a < 3; ++a) {
         if (!(cbox.hi[a] > cbox.lo[a])) continue;
@@ -278,6 +279,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   if (n_faces >= (1u << 24)) { set_error("build_bvh: more than 2^24 faces"); return PTAMD_ERR_LIMIT; }
   if (const char* e = std::getenv("PTAMD_BVH_MAX_LEAF")) max_leaf = (uint32_t)std::atoi(e);   // tuning knobs
   if (const char* e = std::getenv("PTAMD_BVH_ISECT_COST")) g_isect_cost = (float)std::atof(e);
+  if (const char* e = std::getenv("PTAMD_BVH_SWEEP_LIMIT")) g_sweep_limit = (uint32_t)std::atoi(e);   // (2048: round 2's builder)
   if (max_leaf < 1) max_leaf = 1;
   if (max_leaf > 15) max_leaf = 15;
   Builder b;
@@ -501,6 +503,223 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
       for (int i = 0; i < 4; ++i) q[28 + i] = u2f(words[i]);
     }
   }
+
+  // ---- the same tree once more, collapsed to EIGHT children per node with quantised child boxes (layout: ptamd_internal.h,
+  // Bvh::nodes8): one 128-byte line per node again, half the node visits of the four-wide form.
+  {
+    // Which binary nodes become the children of a wide node is decided by the dynamic programme of Ylitie, Karras, Laine
+    // 2017 (section 3.1) instead of round 2's greedy "open the largest child" rule, which left the bottom of the tree full of
+    // wide nodes with two or three leaves (3.1 children per node on the atrium): cost[n][i] = cheapest SAH cost of
+    // representing the subtree of binary node n with at most i child slots of its parent —
+    //   one slot:  a leaf holding all its triangles (if they are at most max_leaf), or a wide node of its own:
+    //              area(n) * c_node + distribute(n, 8);
+    //   i slots:   min(cost[n][i - 1], distribute(n, i)),  distribute(n, j) = min_k cost[left][k] + cost[right][j - k].
+    // A child is a LEAF (its subtree's triangle records are contiguous: leaves were written in depth-first order) or a wide node.
+    const float c_node = 1.0f, c_prim = 0.4f;   // a wide visit ~ 230 VALU + one line, a triangle test ~ 70 VALU + one record
+    const size_t nb = b.nodes.size();
+    std::vector<float> cost(nb * 8, 0.0f);            // [n][i - 1]
+    std::vector<uint8_t> dec(nb * 8, 0);              // i = 1: 0 leaf, 1 wide node; i > 1: 0 = as with i - 1 slots, k = left gets k
+    std::vector<uint8_t> dec8(nb, 0);                 // split of the 8 slots of n's own wide node
+    std::vector<uint32_t> sub_first(nb, 0), sub_count(nb, 0);   // triangle records of the subtree (contiguous)
+    {
+      // post-order over build nodes: children have larger indices than their parent (nodes are appended while recursing)
+      for (size_t i = nb; i-- > 0;) {
+        const BuildNode& bn = b.nodes[i];
+        const float area = bn.box.half_area();
+        float* c = &cost[i * 8];
+        if (bn.left < 0) {
+          sub_first[i] = leaf_info[i] & 0xFFFFFFu;
+          sub_count[i] = leaf_info[i] >> 24;
+          for (int k = 0; k < 8; ++k) c[k] = area * (float)sub_count[i] * c_prim;
+          continue;
+        }
+        const size_t l = (size_t)bn.left, r = (size_t)bn.right;
+        sub_first[i] = std::min(sub_first[l], sub_first[r]);
+        sub_count[i] = sub_count[l] + sub_count[r];
+        float dist[9];
+        uint8_t dk[9];
+        for (int j = 2; j <= 8; ++j) {
+          dist[j] = std::numeric_limits<float>::infinity();
+          dk[j] = 1;
+          for (int k = 1; k < j; ++k) {
+            const float v = cost[l * 8 + (size_t)(k - 1)] + cost[r * 8 + (size_t)(j - k - 1)];
+            if (v < dist[j]) { dist[j] = v; dk[j] = (uint8_t)k; }
+          }
+        }
+        dec8[i] = dk[8];
+        const bool contiguous = sub_first[l] + sub_count[l] == sub_first[r] || sub_first[r] + sub_count[r] == sub_first[l];
+        const float as_leaf = (sub_count[i] <= max_leaf && contiguous) ? area * (float)sub_count[i] * c_prim : std::numeric_limits<float>::infinity();
+        const float as_node = area * c_node + dist[8];
+        c[0] = std::min(as_leaf, as_node);
+        dec[i * 8] = as_leaf <= as_node ? 0 : 1;
+        for (int j = 2; j <= 8; ++j) {
+          if (dist[j] < c[j - 2]) { c[j - 1] = dist[j]; dec[i * 8 + (size_t)(j - 1)] = dk[j]; }
+          else { c[j - 1] = c[j - 2]; dec[i * 8 + (size_t)(j - 1)] = 0; }
+        }
+      }
+    }
+    struct Wide8 { int child[8]; int n; };   // child: build-node id; is_leaf says whether its whole subtree is one leaf
+    std::vector<Wide8> wide;
+    std::vector<uint8_t> child_is_leaf;      // [wide node * 8 + slot]
+    std::vector<int> wide_root;
+    std::vector<uint32_t> wide_depth;
+    wide_root.push_back(0);
+    wide_depth.push_back(1);
+    for (size_t w = 0; w < wide_root.size(); ++w) {      // breadth-first: the top of the tree is contiguous
+      Wide8 wn;
+      wn.n = 0;
+      bool leaf_flag[8] = { false, false, false, false, false, false, false, false };
+      // hand `slots` child slots to the subtree of build node `id`
+      struct Item { int id; int slots; };
+      std::vector<Item> todo;
+      const BuildNode& root = b.nodes[(size_t)wide_root[w]];
+      if (root.left < 0) { leaf_flag[wn.n] = true; wn.child[wn.n++] = wide_root[w]; }
+      else {
+        const int k = dec8[(size_t)wide_root[w]];
+        todo.push_back({ root.right, 8 - k });
+        todo.push_back({ root.left, k });
+      }
+      while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        const BuildNode& bn = b.nodes[(size_t)it.id];
+        if (bn.left < 0) { leaf_flag[wn.n] = true; wn.child[wn.n++] = it.id; continue; }
+        int slots = it.slots;
+        while (slots > 1 && dec[(size_t)it.id * 8 + (size_t)(slots - 1)] == 0) --slots;   // "as with one slot fewer"
+        if (slots == 1) {
+          leaf_flag[wn.n] = dec[(size_t)it.id * 8] == 0;     // merged leaf, or a wide node of its own
+          wn.child[wn.n++] = it.id;
+          continue;
+        }
+        const int k = dec[(size_t)it.id * 8 + (size_t)(slots - 1)];
+        todo.push_back({ bn.right, slots - k });
+        todo.push_back({ bn.left, k });
+      }
+      for (int i = wn.n; i < 8; ++i) wn.child[i] = -1;
+      // Slot assignment (after Ylitie, Karras, Laine: "Efficient incoherent ray traversal on GPUs through compressed wide
+      // BVHs", 2017): slot s stands for the diagonal direction (+-1, +-1, +-1) whose sign bits are s; a child goes to the slot
+      // whose direction matches its offset from the node's centre best, so that for a ray of octant o (bit a: dir[a] < 0)
+      // ascending (slot ^ o) is a front-to-back order — no per-octant table in the node.  Exact assignment by dynamic
+      // programming over slot subsets (8 x 256 states).
+      {
+        Box nb;
+        nb.reset();
+        for (int i = 0; i < wn.n; ++i) nb.grow(b.nodes[(size_t)wn.child[i]].box);
+        float cost[8][8];
+        for (int i = 0; i < 8; ++i)
+          for (int sl = 0; sl < 8; ++sl) {
+            float v = 0.0f;
+            if (i < wn.n) {
+              const Box& cb = b.nodes[(size_t)wn.child[i]].box;
+              for (int a = 0; a < 3; ++a) {
+                const float off = (0.5f * cb.lo[a] + 0.5f * cb.hi[a]) - (0.5f * nb.lo[a] + 0.5f * nb.hi[a]);
+                v += ((sl >> a) & 1) ? off : -off;
+              }
+            }
+            cost[i][sl] = v;
+          }
+        float best[256];
+        int8_t from[8][256];
+        for (int m = 0; m < 256; ++m) best[m] = -std::numeric_limits<float>::infinity();
+        best[0] = 0.0f;
+        // children are placed in index order: after i children the used-slot mask has i bits
+        for (int m = 0; m < 256; ++m) {
+          const int i = __builtin_popcount((unsigned)m);
+          if (i >= 8 || best[m] == -std::numeric_limits<float>::infinity()) continue;
+          for (int sl = 0; sl < 8; ++sl) {
+            if ((m >> sl) & 1) continue;
+            const float v = best[m] + cost[i][sl];
+            const int m2 = m | (1 << sl);
+            if (v > best[m2]) { best[m2] = v; from[i][m2] = (int8_t)sl; }
+          }
+        }
+        int slot_of[8];
+        for (int i = 7, m = 255; i >= 0; --i) { slot_of[i] = from[i][m]; m &= ~(1 << slot_of[i]); }
+        int placed[8];
+        bool placed_leaf[8];
+        for (int sl = 0; sl < 8; ++sl) { placed[sl] = -1; placed_leaf[sl] = false; }
+        for (int i = 0; i < wn.n; ++i) { placed[slot_of[i]] = wn.child[i]; placed_leaf[slot_of[i]] = leaf_flag[i]; }
+        for (int sl = 0; sl < 8; ++sl) { wn.child[sl] = placed[sl]; leaf_flag[sl] = placed_leaf[sl]; }
+      }
+      wide.push_back(wn);
+      for (int sl = 0; sl < 8; ++sl) child_is_leaf.push_back(leaf_flag[sl] ? 1 : 0);
+      out.depth8 = std::max(out.depth8, wide_depth[w]);
+      for (int i = 0; i < 8; ++i)
+        if (wn.child[i] >= 0 && !leaf_flag[i]) {
+          wide_root.push_back(wn.child[i]);
+          wide_depth.push_back(wide_depth[w] + 1);
+        }
+    }
+    std::vector<int> wide_of(b.nodes.size(), -1);
+    for (size_t w = 0; w < wide_root.size(); ++w) wide_of[(size_t)wide_root[w]] = (int)w;
+    out.n_nodes8 = (uint32_t)wide.size();
+    out.nodes8.assign((size_t)out.n_nodes8 * 32, 0u);
+    // the 8-bit planes cost up to one quantisation step of slack per face; the slab arithmetic has two more roundings than
+    // the plain form (scale * 1/d, (origin - o) / d): the boxes are inflated by twice the origin-dependent margin first
+    const float m8 = margin + 2.0f * origin_margin;
+    for (size_t w = 0; w < wide.size(); ++w) {
+      uint32_t* q = &out.nodes8[w * 32];
+      float lo_c[8][3], hi_c[8][3];
+      float nlo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, nhi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+      for (int c = 0; c < 8; ++c) {
+        if (wide[w].child[c] < 0) continue;
+        const BuildNode& cn = b.nodes[(size_t)wide[w].child[c]];
+        for (int a = 0; a < 3; ++a) {
+          lo_c[c][a] = cn.box.lo[a] - (m8 + std::fabs(cn.box.lo[a]) * 1e-6f);
+          hi_c[c][a] = cn.box.hi[a] + (m8 + std::fabs(cn.box.hi[a]) * 1e-6f);
+          nlo[a] = std::min(nlo[a], lo_c[c][a]);
+          nhi[a] = std::max(nhi[a], hi_c[c][a]);
+        }
+      }
+      uint32_t expo[3];
+      float scale[3];
+      for (int a = 0; a < 3; ++a) {
+        // smallest power of two with (extent / scale) <= 255, kept inside the normal range; NaN / inf extents: the largest
+        int e = 0;
+        const float ext = nhi[a] - nlo[a];
+        if (ext > 0.0f && ext <= std::numeric_limits<float>::max()) { (void)std::frexp(ext / 255.0f, &e); }   // ext / 255 = m * 2^e, m in [0.5, 1) -> 2^e >= ext / 255
+        else if (!(ext <= std::numeric_limits<float>::max())) e = 120;
+        else e = -120;
+        e = std::max(-120, std::min(120, e));
+        expo[a] = (uint32_t)(e + 127);
+        scale[a] = std::ldexp(1.0f, e);
+        q[a] = f2u(nlo[a]);
+      }
+      q[3] = expo[0] | (expo[1] << 8) | (expo[2] << 16) | ((uint32_t)wide[w].n << 24);
+      uint8_t qlo[3][8], qhi[3][8];
+      for (int c = 0; c < 8; ++c) {
+        uint32_t ref = 0xFFFFFFFFu;
+        if (wide[w].child[c] < 0) {
+          for (int a = 0; a < 3; ++a) { qlo[a][c] = 255; qhi[a][c] = 0; }   // inverted: no ray enters before it leaves
+        } else {
+          for (int a = 0; a < 3; ++a) {
+            // rounded outward, then checked with the device's own decode: fma(q, scale, origin) must enclose the child
+            int l = (int)std::floor((lo_c[c][a] - nlo[a]) / scale[a]);
+            int h = (int)std::ceil((hi_c[c][a] - nlo[a]) / scale[a]);
+            l = std::max(0, std::min(255, l));
+            h = std::max(0, std::min(255, h));
+            while (l > 0 && !(std::fma((float)l, scale[a], nlo[a]) <= lo_c[c][a])) --l;
+            while (h < 255 && !(std::fma((float)h, scale[a], nlo[a]) >= hi_c[c][a])) ++h;
+            qlo[a][c] = (uint8_t)l;
+            qhi[a][c] = (uint8_t)h;
+          }
+          if (child_is_leaf[w * 8 + (size_t)c]) {
+            // (possibly several binary leaves merged: their triangle records follow each other)
+            const size_t id = (size_t)wide[w].child[c];
+            ref = 0x80000000u | (sub_count[id] << 24) | sub_first[id];
+            out.max_leaf8 = std::max(out.max_leaf8, sub_count[id]);
+          } else {
+            ref = (uint32_t)wide_of[(size_t)wide[w].child[c]];
+          }
+        }
+        q[4 + c] = ref;
+      }
+      for (int a = 0; a < 3; ++a) {
+        std::memcpy(&q[12 + a * 2], qlo[a], 8);
+        std::memcpy(&q[18 + a * 2], qhi[a], 8);
+      }
+    }
+  }
   return PTAMD_OK;
 }
 
@@ -591,6 +810,93 @@ void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], 
   out.t = best_t; out.u = best_u; out.v = best_v;
 }
 
+// Mirror of the device's eight-wide walk (csrc/pt_kernels.hip: walk8_*): child boxes decoded from the node's origin, per-axis
+// power-of-two scale and 8-bit planes with the device's operations (A = scale / d, B = fma(origin, 1/d, -o/d),
+// t = fma(plane, A, B)); hit children stacked farthest first in ascending (slot ^ octant) order; entries beyond the best hit
+// dropped when popped.  Result contract as for the other walks.
+void bvh8_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
+                     uint64_t* tris_tested)
+{
+  const float MAX_DIST = 100000.0f;
+  float best_t = MAX_DIST, best_u = 0.f, best_v = 0.f;
+  uint32_t best_idx = 0xFFFFFFFFu;
+  // octant from the SIGN BITS (-0.0 counts as negative: its stand-in below is -1e-30, so the ray enters through the high plane)
+  const uint32_t oct = (std::signbit(dir[0]) ? 1u : 0u) | (std::signbit(dir[1]) ? 2u : 0u) | (std::signbit(dir[2]) ? 4u : 0u);
+  float inv[3], noi[3];
+  for (int a = 0; a < 3; ++a) {
+    const float da = std::fabs(dir[a]) < 1e-30f ? std::copysign(1e-30f, dir[a]) : dir[a];
+    inv[a] = 1.0f / da;
+    noi[a] = -(origin[a] * inv[a]);
+  }
+  struct Entry { uint32_t ref; float tnear; };
+  std::vector<Entry> stack;
+  if (bvh.n_nodes8) stack.push_back({ 0u, 0.0f });
+  while (!stack.empty()) {
+    const Entry e = stack.back();
+    stack.pop_back();
+    if (!(e.tnear <= best_t)) continue;
+    if (e.ref & 0x80000000u) {
+      const uint32_t first = e.ref & 0xFFFFFFu, count = (e.ref >> 24) & 0x7Fu;
+      for (uint32_t k = 0; k < count; ++k) {
+        const float* t = &bvh.tris[(size_t)(first + k) * 12];
+        if (tris_tested) ++*tris_tested;
+        const float e1[3] = { t[0], t[1], t[2] }, e2[3] = { t[3], t[4], t[5] }, v0[3] = { t[6], t[7], t[8] };
+        const float p[3] = { dir[1] * e2[2] - dir[2] * e2[1], dir[2] * e2[0] - dir[0] * e2[2], dir[0] * e2[1] - dir[1] * e2[0] };
+        const float det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+        if (det < 1e-7f) continue;
+        const float inv_det = 1.0f / det;
+        const float tv[3] = { origin[0] - v0[0], origin[1] - v0[1], origin[2] - v0[2] };
+        const float u = (tv[0] * p[0] + tv[1] * p[1] + tv[2] * p[2]) * inv_det;
+        if (u < 0 || u > 1) continue;
+        const float qv[3] = { tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0] };
+        const float v = (dir[0] * qv[0] + dir[1] * qv[1] + dir[2] * qv[2]) * inv_det;
+        if (v < 0 || u + v > 1) continue;
+        const float tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * inv_det;
+        uint32_t idx;
+        std::memcpy(&idx, &t[9], 4);
+        if (tt > 0.0f && (tt < best_t || (tt == best_t && idx < best_idx && best_idx != 0xFFFFFFFFu))) {
+          best_t = tt; best_u = u; best_v = v; best_idx = idx;
+        }
+      }
+      continue;
+    }
+    const uint32_t* q = &bvh.nodes8[(size_t)e.ref * 32];
+    if (nodes_visited) {
+      ++*nodes_visited;
+      if (e.ref < 73u) ++nodes_visited[3];    // counters[3], [4]: visits to the first 73 / 585 nodes (three / four full levels)
+      if (e.ref < 585u) ++nodes_visited[4];
+    }
+    float A[3], B[3];
+    for (int a = 0; a < 3; ++a) {
+      const float scale = u2f(((q[3] >> (8 * a)) & 0xFFu) << 23);
+      A[a] = scale * inv[a];
+      B[a] = std::fma(u2f(q[a]), inv[a], noi[a]);
+    }
+    const uint8_t* planes = reinterpret_cast<const uint8_t*>(q + 12);   // lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8]
+    uint32_t hit = 0;
+    float tn[8];
+    for (int c = 0; c < 8; ++c) {
+      float tnear = 0.0f, tfar = best_t;
+      for (int a = 0; a < 3; ++a) {
+        const float tl = std::fma((float)planes[a * 8 + c], A[a], B[a]), th = std::fma((float)planes[24 + a * 8 + c], A[a], B[a]);
+        const bool neg = (oct >> a) & 1u;     // the ray runs against this axis: it enters through the high plane
+        tnear = std::max(tnear, neg ? th : tl);
+        tfar = std::min(tfar, neg ? tl : th);
+      }
+      tn[c] = tnear;
+      if (tnear <= tfar) hit |= 1u << c;
+    }
+    // stack order: farthest first = descending (slot ^ octant); the nearest hit child ends on top
+    for (int f = 7; f >= 0; --f) {
+      const int c = f ^ (int)oct;
+      if ((hit >> c) & 1u) stack.push_back({ q[4 + c], tn[c] });
+    }
+  }
+  out.kind = best_idx == 0xFFFFFFFFu ? 0 : 1;
+  out.index = best_idx == 0xFFFFFFFFu ? -1 : (int32_t)best_idx;
+  out.t = best_t; out.u = best_u; out.v = best_v;
+}
+
 // Mirror of the device traversal (csrc/pt_kernels.hip: traverse_bvh); float ops in the same
 // order.  Only the final (kind, index, t) has to agree with brute force — the set of
 // visited nodes is an implementation detail.
@@ -669,6 +975,26 @@ void bvh_trace_host(const Bvh& bvh, const ptamd_face* faces, const float dir[3],
 }
 
 } // namespace ptamd
+
+extern "C" int ptamd_host_bvh8_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
+                                     int32_t* out, uint64_t* counters)
+{
+  if ((n_faces && !faces) || (n && (!rays || !out))) { ptamd::set_error("ptamd_host_bvh8_trace: null argument"); return PTAMD_ERR_ARG; }
+  ptamd::Bvh bvh;
+  int rc = ptamd::build_bvh(faces, n_faces, 1e-3f, 3, bvh);
+  if (rc != PTAMD_OK) return rc;
+  for (uint32_t i = 0; i < n; ++i) {
+    ptamd::HostHit h;
+    ptamd::bvh8_trace_host(bvh, rays + (size_t)i * 6, rays + (size_t)i * 6 + 3, h,
+                           counters ? &counters[0] : nullptr, counters ? &counters[1] : nullptr);
+    out[i * 4 + 0] = h.kind;
+    out[i * 4 + 1] = h.index;
+    std::memcpy(&out[i * 4 + 2], &h.t, 4);
+    out[i * 4 + 3] = 0;
+  }
+  if (counters) { counters[2] = bvh.depth8; counters[5] = bvh.n_nodes8; }
+  return PTAMD_OK;
+}
 
 extern "C" int ptamd_host_bvh4_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                                      int32_t* out, uint64_t* counters)

@@ -73,6 +73,18 @@ struct Bvh {
   // Nodes are numbered breadth-first (node 0 = root).  Leaves point into `tris`.
   std::vector<float> nodes4;
   uint32_t n_nodes4 = 0, depth4 = 0;
+  // ... and with EIGHT children per node and quantised child boxes: the walk of scenes that do not fit in LDS.  node record =
+  // 32 dwords = ONE 128-byte line:
+  //   [0..2]   origin (float): the low corner of the node's (inflated) box      [3] exponent bytes ex | ey << 8 | ez << 16
+  //            (scale[a] = 2^(e[a] - 127)), child count << 24
+  //   [4..11]  reference[8]: 0xFFFFFFFF empty | node index | 0x80000000 | count << 24 | first triangle (leaf)
+  //   [12..17] low planes  x[8] y[8] z[8], one byte per child       [18..23] high planes x[8] y[8] z[8]
+  //            child box = origin + plane * scale, low planes rounded down, high planes up (the inflated child box is inside)
+  //   [24..31] unused
+  // Children sit in slots by direction (slot bits = signs of their offset from the node's centre), so that ascending
+  // (slot ^ ray octant) is a front-to-back order.  Breadth-first numbering as for nodes4.
+  std::vector<uint32_t> nodes8;
+  uint32_t n_nodes8 = 0, depth8 = 0, max_leaf8 = 0;
   float extent = 0.0f;           // largest finite |coordinate| of the scene
   bool all_finite = true;        // no vertex coordinate is NaN or infinite
   float margin_floor = 0.0f;     // smallest inflation any box face received (absolute margin + extent * 2^-20)
@@ -87,6 +99,8 @@ struct HostHit { int32_t kind; int32_t index; float t; float u, v; };
 void bvh_trace_host(const Bvh& bvh, const ptamd_face* faces, const float dir[3], const float origin[3],
                     HostHit& out, uint64_t* nodes_visited, uint64_t* tris_tested);
 void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
+                     uint64_t* tris_tested);
+void bvh8_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
                      uint64_t* tris_tested);
 
 } // namespace ptamd

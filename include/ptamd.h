@@ -341,6 +341,12 @@ int ptamd_host_bvh_trace(const ptamd_face* faces, uint32_t n_faces, const float*
 int ptamd_host_bvh4_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                           int32_t* out, uint64_t* counters);
 
+/* ... and for the eight-wide form with quantised child boxes (one 128-byte line per node: origin, per-axis power-of-two
+ * scale, 8-bit planes), built with leaves of at most three triangles as the device uses it.  counters (optional, 6 words):
+ * [0] += nodes visited, [1] += triangles tested, [2] = depth, [3] / [4] += visits to the first 73 / 585 nodes, [5] = node count. */
+int ptamd_host_bvh8_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
+                          int32_t* out, uint64_t* counters);
+
 /* Plain device-memory helpers so that C/C++ hosts need not link HIP themselves. */
 int ptamd_device_alloc(ptamd_context* ctx, size_t bytes, void** out);
 int ptamd_device_free(ptamd_context* ctx, void* p);
