@@ -226,6 +226,11 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
 // `state` is the walk's position in the loop's own terms (below): the LDS address of the next box, or 0xFFFF when the walk is
 // over; it stays in that form between the box phases of a round (traverse_round) — converting it to a node index and
 // back costs four VALU per phase.
+// The loop names its scratch registers (v64..v69, v72, v74: a ds_read_b128 needs four consecutive ones, which an inline-asm operand
+// cannot express dword by dword); they are in the clobber list, so the allocator keeps everything else out of them.  They must exist
+// in every kernel that inlines this loop: 75 VGPRs at least, i.e. at most 6 waves per SIMD (512 / 6 = 85) — checked here at build time.
+static_assert(PT_TILE_WAVES_PER_EU <= 6 && PT_PERSISTENT_WAVES_PER_EU <= 6 && PT_RS_WAVES_PER_EU <= 6 && PT_SP_WAVES_PER_EU <= 6,
+              "walk_to_leaf_lds_state clobbers v64..v74: kernels that inline it need a budget of at least 75 VGPRs (<= 6 waves per SIMD)");
 PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w, uint32_t& leaf_first, uint32_t& leaf_count, uint32_t walk_min)
 {
   // COMPACT LDS nodes (stage_scene), two arrays of 32-byte records, N nodes each:

@@ -23,6 +23,13 @@ static thread_local std::string g_last_error;
 
 void set_error(const std::string& msg) { g_last_error = msg; }
 
+const char* tuning_env(const char* name)
+{
+  const char* gate = std::getenv("PTAMD_TUNING");
+  if (!gate || std::atoi(gate) != 1) return nullptr;
+  return std::getenv(name);
+}
+
 namespace {
 
 struct DeviceScene {
@@ -431,7 +438,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       uint32_t treelet = ctx->treelet_nodes < s.n_nodes4 ? ctx->treelet_nodes : s.n_nodes4;
       if (treelet * 128u + waves * 512u * 4u + pools > share) treelet = (share - pools - waves * 512u * 4u) / 128u;   // keep >= 4 stack entries
       uint32_t fit = (share - pools - treelet * 128u) / (waves * 512u);
-      if (const char* ev = std::getenv("PTAMD_STACK_LDS")) { int v = std::atoi(ev); if (v >= 1 && (uint32_t)v <= fit) fit = (uint32_t)v; }   // tuning knob
+      if (const char* ev = tuning_env("PTAMD_STACK_LDS")) { int v = std::atoi(ev); if (v >= 1 && (uint32_t)v <= fit) fit = (uint32_t)v; }   // tuning knob
       p.treelet_nodes = treelet;
       p.stack_lds_entries = need < fit ? need : fit;
       p.stack_spill_entries = need - p.stack_lds_entries;
@@ -621,7 +628,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   PT_HIP(hipMemset(ctx->d_heads, 0, (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
   ctx->heads_clean.assign(kTicketRing, true);
   {
-    const char* e = std::getenv("PTAMD_GAMMA_TABLE"); // tuning knob: 0 = pt_powf for every pixel
+    const char* e = tuning_env("PTAMD_GAMMA_TABLE"); // tuning knob: 0 = pt_powf for every pixel
     if (!e || std::atoi(e) != 0) {
       PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_gamma), 258 * sizeof(float)));
       hipError_t ge = build_gamma_table(ctx->d_gamma, nullptr);
@@ -629,7 +636,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
       if (ge != hipSuccess) return hip_fail("ptamd_create: gamma table", ge);
     }
   }
-  if (const char* e = std::getenv("PTAMD_OVERLAP")) ctx->overlap = std::atoi(e) != 0; // tuning knob
+  if (const char* e = tuning_env("PTAMD_OVERLAP")) ctx->overlap = std::atoi(e) != 0; // tuning knob
   if (ctx->overlap) {
     // the two internal streams of the launch pipeline, with their hardware queues brought up now (a stream's first
     // operation costs ~6 ms on this runtime: it would otherwise land in the frame where a host starts to run ahead)
@@ -642,37 +649,37 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   hipDeviceProp_t prop;
   PT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   ctx->n_cus = prop.multiProcessorCount;
-  if (const char* e = std::getenv("PTAMD_REFILL_MIN")) { // tuning knob
+  if (const char* e = tuning_env("PTAMD_REFILL_MIN")) { // tuning knob
     int v = std::atoi(e);
     ctx->refill_min = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
-  if (const char* e = std::getenv("PTAMD_DEFAULT_KERNEL")) { // tuning knob: 1..6
+  if (const char* e = tuning_env("PTAMD_DEFAULT_KERNEL")) { // tuning knob: 1..6
     int v = std::atoi(e);
     if (v >= 1 && v <= 6) { ctx->default_kernel = (uint32_t)v; ctx->default_kernel_is_builtin = false; }
   }
-  if (const char* e = std::getenv("PTAMD_ROUND_MIN")) { // tuning knob
+  if (const char* e = tuning_env("PTAMD_ROUND_MIN")) { // tuning knob
     int v = std::atoi(e);
     ctx->round_min = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
-  if (const char* e = std::getenv("PTAMD_WALK_MIN")) { // tuning knob
+  if (const char* e = tuning_env("PTAMD_WALK_MIN")) { // tuning knob
     int v = std::atoi(e);
     ctx->walk_min = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
-  if (const char* e = std::getenv("PTAMD_WALK_MIN4")) { // tuning knob
+  if (const char* e = tuning_env("PTAMD_WALK_MIN4")) { // tuning knob
     int v = std::atoi(e);
     ctx->walk_min4 = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
-  if (const char* e = std::getenv("PTAMD_SHORT_RCP")) ctx->short_rcp = std::atoi(e) != 0; // tuning knob
-  if (const char* e = std::getenv("PTAMD_POOL_LDS")) ctx->pool_in_lds = std::atoi(e) != 0; // tuning knob
-  if (const char* e = std::getenv("PTAMD_TREELET")) { // tuning knob
+  if (const char* e = tuning_env("PTAMD_SHORT_RCP")) ctx->short_rcp = std::atoi(e) != 0; // tuning knob
+  if (const char* e = tuning_env("PTAMD_POOL_LDS")) ctx->pool_in_lds = std::atoi(e) != 0; // tuning knob
+  if (const char* e = tuning_env("PTAMD_TREELET")) { // tuning knob
     int v = std::atoi(e);
     ctx->treelet_nodes = (uint32_t)(v < 0 ? 0 : (v > 1024 ? 1024 : v));
   }
-  if (const char* e = std::getenv("PTAMD_ROUND_DIV")) { // tuning knob
+  if (const char* e = tuning_env("PTAMD_ROUND_DIV")) { // tuning knob
     int v = std::atoi(e);
     ctx->round_div = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
-  if (const char* e = std::getenv("PTAMD_TILES_PER_TICKET")) {
+  if (const char* e = tuning_env("PTAMD_TILES_PER_TICKET")) {
     int v = std::atoi(e);
     ctx->tiles_per_ticket = (uint32_t)(v < 1 ? 1 : (v > 1024 ? 1024 : v));
   }

@@ -273,13 +273,13 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   out = Bvh();
   float split_alpha = 0.0f;   // pre-splitting off unless asked for (tuning knobs)
   uint32_t split_budget = n_faces / 2u + 16u;
-  if (const char* e = std::getenv("PTAMD_BVH_SPLIT_ALPHA")) split_alpha = (float)std::atof(e);
-  if (const char* e = std::getenv("PTAMD_BVH_SPLIT_BUDGET")) split_budget = (uint32_t)std::atoi(e);
+  if (const char* e = tuning_env("PTAMD_BVH_SPLIT_ALPHA")) split_alpha = (float)std::atof(e);
+  if (const char* e = tuning_env("PTAMD_BVH_SPLIT_BUDGET")) split_budget = (uint32_t)std::atoi(e);
   if (n_faces == 0) return PTAMD_OK;
   if (n_faces >= (1u << 24)) { set_error("build_bvh: more than 2^24 faces"); return PTAMD_ERR_LIMIT; }
-  if (const char* e = std::getenv("PTAMD_BVH_MAX_LEAF")) max_leaf = (uint32_t)std::atoi(e);   // tuning knobs
-  if (const char* e = std::getenv("PTAMD_BVH_ISECT_COST")) g_isect_cost = (float)std::atof(e);
-  if (const char* e = std::getenv("PTAMD_BVH_SWEEP_LIMIT")) g_sweep_limit = (uint32_t)std::atoi(e);   // (2048: round 2's builder)
+  if (const char* e = tuning_env("PTAMD_BVH_MAX_LEAF")) max_leaf = (uint32_t)std::atoi(e);   // tuning knobs
+  if (const char* e = tuning_env("PTAMD_BVH_ISECT_COST")) g_isect_cost = (float)std::atof(e);
+  if (const char* e = tuning_env("PTAMD_BVH_SWEEP_LIMIT")) g_sweep_limit = (uint32_t)std::atoi(e);   // (2048: round 2's builder)
   if (max_leaf < 1) max_leaf = 1;
   if (max_leaf > 15) max_leaf = 15;
   Builder b;

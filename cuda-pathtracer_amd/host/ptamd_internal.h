@@ -10,6 +10,11 @@ namespace ptamd {
 
 void set_error(const std::string& msg);
 
+// Every tuning / A-B knob of the library (PTAMD_ROUND_MIN, PTAMD_OVERLAP, PTAMD_BVH_MAX_LEAF, ...) is an environment variable that
+// is read ONLY when PTAMD_TUNING=1 is set too: a production host's environment cannot change how the library renders.
+// Returns the variable's value, or nullptr when it is unset or tuning is off.
+const char* tuning_env(const char* name);
+
 // Output of the host loader: the flattened arrays ptamd_scene_desc points into.
 struct HostScene {
   std::vector<ptamd_face> faces;

@@ -260,7 +260,21 @@ typedef struct {
 /* Asynchronous on launch->stream.  Once a configuration (frame size, frame_count, stream) has been launched once — the
  * first launch sizes that stream's sample scratch, which synchronises and allocates — later launches only enqueue
  * kernels and memsets, so a host may capture them into a hipGraph (hipStreamBeginCapture on launch->stream) and replay it:
- * tests/test_gpu_parity.py test_batched_launch_is_graph_capturable.  The captured launch keeps its frame_nb / seeds. */
+ * tests/test_gpu_parity.py test_batched_launch_is_graph_capturable.  The captured launch keeps its frame_nb / seeds.
+ * What a captured launch pins: its stream's in-stream sample slab and its ring slot of tile-ticket heads are baked into the
+ * graph.  While the graph is alive the caller must not (a) issue a LARGER launch on that stream (the slab would be reallocated:
+ * replays would write freed memory), (b) use more than 16 streams with batched launches on the context (the 17th drops every
+ * slab), (c) let more than 1024 other launches of the context pass between two replays that may run concurrently with eager
+ * launches (the ring slot comes round again).  Eager launches of the same or a smaller configuration on the same stream are
+ * fine: stream order protects the slab, and launches the library pipelines (below) use slabs of their own.
+ *
+ * Back-to-back launches.  A host that issues launches of the default kernel on ONE stream without waiting for them (the
+ * reference's render loop does not wait: gpu_processor.cpp:365-386) gets them pipelined by the library: when the stream's
+ * previous launch has not finished, the new one is sized to half the GPU and its path-tracing kernel runs on an internal stream,
+ * its accumulate / tonemap pass on the caller's stream behind an event — two launches are then resident side by side and
+ * the tail of one is covered by the bulk of the next.  Stream semantics are unchanged: everything the launch writes that the
+ * caller can see (accumulator, surface) is written on the caller's stream, in order.  Not applied when machine_share > 1 (the
+ * caller runs its own pipeline), during graph capture, or for ptamd_raytrace_stats. */
 int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch);
 /* Rows an interleaved launch renders (= rows its band-local buffers must hold): the bands j = rank, rank + ranks, ... of
  * band_rows rows each, the last band of the frame possibly shorter. */

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 # The GPU parity suite under alternative scheduling knobs (ticket size, refill / round / walk thresholds, default kernel,
 # stack and treelet sizes of the four-wide walk, pools in global memory, full division in the triangle test, pt_powf instead of the gamma table).  Under a pinned default kernel that cannot batch frames
 # (PTAMD_DEFAULT_KERNEL=1/2/4) the batched cases skip themselves (tests/test_gpu_parity.py: batched_ok).

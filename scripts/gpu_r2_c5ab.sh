@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 # configs[4] (3840x2160, 16 spp, 8 bounces, aperture 0.113) with and without the short reciprocal, same box
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 python -c "import __graft_entry__ as g; g.build()" || exit 1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 # Round-2 first GPU session: GPU tests (new full-size configs), exec-mask micro-benchmark, the new bench line,
 # refill_min A/B on the headline config.
 set -o pipefail

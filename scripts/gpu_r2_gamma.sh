@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 # the gamma step of the resolve pass as a table (default) against pt_powf per channel (PTAMD_GAMMA_TABLE=0): parity both ways, A/B
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 python -c "import __graft_entry__ as g; g.build()" || exit 1

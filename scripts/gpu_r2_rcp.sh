@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 # A/B of the 7-instruction exact reciprocal in the restart kernel's triangle test (PTAMD_SHORT_RCP=0/1), after the parity suite
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 python -c "import __graft_entry__ as g; g.build()" || exit 1

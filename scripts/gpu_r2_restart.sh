@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 # Restart kernel bring-up: parity first (smoke with a hard time limit: a kernel that never ends must not take the run with it),
 # then A/B against the persistent kernel over the round threshold.
 set -o pipefail

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 # Restart kernel: knob sweep, then compile-time variants (block size / waves per SIMD).
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 run() { label=$1; shift

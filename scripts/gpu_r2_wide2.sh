@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 run() { label=$1; shift
   env "$@" timeout -k 10 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extra --kernel restart $BARGS 2>>$OUT/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$label', d['value'], d['ms_per_step'], r['kernel_ms_per_launch'], r['nodes_per_ray'], r['tris_per_ray'])"

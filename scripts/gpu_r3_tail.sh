@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 # round 3: shared pools + launch overlap.  smoke, GPU suite, launch timelines with / without pool sharing, bench with / without overlap
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 # kernel start / end times of back-to-back launches on one stream (does the library's pipelining overlap them?)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}

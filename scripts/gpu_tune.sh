@@ -1,4 +1,5 @@
 #!/bin/bash
+export PTAMD_TUNING=1   # the knobs below are read only with this set
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 run() { timeout -k 10 120 python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" 2>>$OUT/bench.err | python -c "
 import json,sys

@@ -96,9 +96,13 @@ assert (got == O.intersect(sc, rays)).all()
 print(nodes, tris)
 """
     base = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
-    env = dict(os.environ, PTAMD_BVH_SPLIT_ALPHA="0.01", PTAMD_BVH_SPLIT_BUDGET="200")
+    env = dict(os.environ, PTAMD_TUNING="1", PTAMD_BVH_SPLIT_ALPHA="0.01", PTAMD_BVH_SPLIT_BUDGET="200")
     split = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=env).stdout.split()
     assert base != split          # the knob did change the tree
+    # ... and only behind PTAMD_TUNING=1: a production environment cannot change the tree
+    ungated = dict(os.environ, PTAMD_BVH_SPLIT_ALPHA="0.01", PTAMD_BVH_SPLIT_BUDGET="200")
+    ungated.pop("PTAMD_TUNING", None)
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=ungated).stdout.split() == base
 
 
 # ------------------------------------------------------------------ the four-wide form (scenes walked from L2)

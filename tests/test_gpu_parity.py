@@ -380,6 +380,7 @@ def test_wide_walk_with_a_spilling_stack(P, O, gpu_ctx, monkeypatch):
     hs = make_scene(P, random_soup(rng, 2500, extent=2.5, size=0.3), lights=[((0.0, 3.0, 1.0), (1, 1, 1), 6.0, 0.7)])
     cube = synthetic_cubemap(rng, 4)
     ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 96, 64, spp=2, bounces=4)
+    monkeypatch.setenv("PTAMD_TUNING", "1")
     monkeypatch.setenv("PTAMD_STACK_LDS", "2")
     acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 96, 64, 2, 4, P.KERNEL_BVH_RESTART)
     assert_same(acc, rgba, *ref, "wide walk, stack mostly in the global slab")
