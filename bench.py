@@ -81,6 +81,9 @@ def parse_args(argv=None):
                          "buffering, as the reference double-buffers its GL renderbuffers: driver/interop.cpp:107-111).  "
                          "0 = auto: 2 on one GPU, 4 on several GPUs (the RCCL all-gather of frame i overlaps the render of "
                          "the next ones); each launch is sized to 1/n of the GPU (ptamd_launch.machine_share)")
+    ap.add_argument("--machine-share", type=int, default=0,
+                    help="size every launch to 1/K of the GPU whatever the number of frames in flight (default: K = frames in flight): "
+                         "with more frames in flight than shares, the queued workgroups of one launch fill the tails and kernel gaps of the others")
     ap.add_argument("--no-share", dest="share", action="store_false",
                     help="with several frames in flight, size every launch to the whole GPU instead of its 1/n share")
     ap.add_argument("--sequential", action="store_true", help="one launch per spp instead of one batched launch per frame")
@@ -215,7 +218,7 @@ class Workload:
     """A frame configuration on this rank: scene uploaded once, `n_slots` frames in flight (buffers + stream each)."""
 
     def __init__(self, P, torch, dist, hs, cube, W, H, spp, B, kernel_name, n_slots, share, batched, local_rank,
-                 world=1, rank=0, gather=False, rows=None, interleave=None):
+                 world=1, rank=0, gather=False, rows=None, interleave=None, machine_share=0):
         """interleave = (ranks, rank, band_rows): this rank owns interleaved bands instead of rows [y0, y1)."""
         self.P, self.torch, self.dist = P, torch, dist
         self.W, self.H, self.spp, self.B = W, H, spp, B
@@ -245,7 +248,7 @@ class Workload:
                 bg = P.BandGather(H, W, world, rank, self.dev, interleave=interleave[2] if interleave is not None else 0)
             # the renderer writes its rows straight into the collective's send buffer: no staging copy per frame
             fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(self.y0, self.y1),
-                                 band_local=True, machine_share=n_slots if (share and n_slots > 1) else 0, interleave=interleave,
+                                 band_local=True, machine_share=(machine_share if machine_share > 0 else n_slots) if (share and n_slots > 1) else 0, interleave=interleave,
                                  surface=bg.send_rows() if bg is not None else None)
             st = torch.cuda.current_stream() if n_slots == 1 else torch.cuda.Stream(device=self.dev)
             self.slots.append((fr, bg, st))
@@ -426,7 +429,7 @@ def main():
     elif world > 1 and ilv_rows:
         interleave = (world, rank, ilv_rows)
     wl = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, n_slots, args.share, not args.sequential,
-                  local_rank, world, rank, gather, rows, interleave)
+                  local_rank, world, rank, gather, rows, interleave, machine_share=args.machine_share)
     proxy = rows is not None or (interleave is not None and world == 1)
     dt, step_ms = wl.run(args.steps, args.warmup, args.settle_ms)
     gather_ms = wl.gather_ms() if (world > 1 or force_gather) else None

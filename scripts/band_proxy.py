@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--ranks", type=int, nargs="+", default=[8, 4, 2])
 ap.add_argument("--in-flight", type=int, nargs="+", default=[1, 3, 4])
 ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--machine-share", type=int, default=0, help="passed to bench.py (0: = frames in flight)")
 ap.add_argument("--interleave", type=int, default=0, help="interleaved bands of this many rows instead of contiguous bands")
 ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_band_proxy.json"))
 args = ap.parse_args()
@@ -31,7 +32,7 @@ for n in args.ranks:
             env = dict(os.environ, PTAMD_BENCH_FORCE_GATHER="1")
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--as-rank", f"{r}/{n}", "--interleave", str(args.interleave),
                                   "--steps", str(args.steps), "--warmup", "5", "--no-cpu-baseline", "--no-extra",
-                                  "--frames-in-flight", str(fif)], env=env, capture_output=True, text=True, timeout=300)
+                                  "--frames-in-flight", str(fif), "--machine-share", str(args.machine_share)], env=env, capture_output=True, text=True, timeout=300)
             if out.returncode != 0:
                 print(out.stderr[-2000:], file=sys.stderr)
                 raise SystemExit(f"bench failed for rank {r}/{n}")
