@@ -178,3 +178,27 @@ def test_native_load_brings_torch_in_first():
             "P.native.load(); assert 'torch' in sys.modules; print('ok')" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_bench_refuses_counters_of_another_build(tmp_path):
+    """bench.py prices its roofline with PMC counters only when they were collected on THIS build of the device code
+    (ptamd_build_id, stamped into profiles/pmc_latest.json by scripts/summarize_pmc.py)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = {"build_id": "0123456789abcdef", "kernel": "restart", "scene": "indoor.scene", "workload": "1920x1080", "spp": 4, "bounces": 4,
+           "frames_per_launch": 4, "valu_insts_per_sample": 85.0}
+    path = tmp_path / "pmc.json"
+    path.write_text(json.dumps(rec))
+    same = bench.load_pmc(str(path), "restart", 1920, 1080, 4, 4, 4, 1, "indoor.scene", "0123456789abcdef")
+    other = bench.load_pmc(str(path), "restart", 1920, 1080, 4, 4, 4, 1, "indoor.scene", "fedcba9876543210")
+    assert same is not None and same["stale"] is False
+    assert other is not None and other["stale"] is True
+    assert bench.load_pmc(str(path), "restart", 1280, 720, 4, 4, 4, 1, "indoor.scene", "0123456789abcdef") is None   # another workload
+    import cuda_pathtracer_amd as P
+    bid = P.native.load().ptamd_build_id().decode()
+    assert len(bid) == 16 and all(c in "0123456789abcdef" for c in bid) and bid in P.native.load().ptamd_version().decode()
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    assert "build_id" in committed

@@ -838,6 +838,36 @@ def test_stats_are_consistent(P, O, gpu_ctx, indoor):
     assert s_bf["tris_tested"] >= s_bvh["tris_tested"] * 20 and s_bvh["nodes_visited"] > 0
 
 
+def test_launch_timeline_stamps(P, gpu_ctx, indoor):
+    """ptamd_set_timeline: the time-stamp instantiation of the default kernel renders the same pixels and records, per wave,
+    entry <= scene staged <= (no ticket left) <= exit; switched off, nothing is recorded."""
+    import torch
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    W, H, B = 640, 360, 4
+    want = gpu_render(P, gpu_ctx, indoor, cube, W, H, 1, B, P.KERNEL_BVH_RESTART, ids=ids)
+    n_waves = 256 * 24
+    gpu_ctx.set_timeline(n_waves)
+    try:
+        got = gpu_render(P, gpu_ctx, indoor, cube, W, H, 1, B, P.KERNEL_BVH_RESTART, ids=ids)
+        tl, khz = gpu_ctx.read_timeline(n_waves)
+    finally:
+        gpu_ctx.set_timeline(0)
+    assert_same(*got, *want, "time-stamp instantiation")
+    live = tl[:, 3] != 0
+    assert khz > 0 and 12 <= live.sum() <= n_waves
+    t = tl[live].astype(np.int64)
+    assert (t[:, 0] <= t[:, 1]).all() and (t[:, 1] <= t[:, 3]).all()
+    dry = t[:, 2] != 0
+    assert dry.any() and (t[dry, 1] <= t[dry, 2]).all() and (t[dry, 2] <= t[dry, 3]).all()
+    assert (t[:, 3].max() - t[:, 0].min()) / khz < 50.0          # the launch lasted less than 50 ms
+    # off again: launches record nothing (the buffer is gone; reading it is an error)
+    gpu_render(P, gpu_ctx, indoor, cube, W, H, 1, B, P.KERNEL_BVH_RESTART, ids=ids)
+    with pytest.raises(P.PtamdError):
+        gpu_ctx.read_timeline(16)
+    torch.cuda.synchronize()
+
+
 def test_error_behaviour(P, gpu_ctx, indoor):
     """Bad arguments come back as status codes with a message; nothing is launched."""
     import torch
