@@ -1207,7 +1207,10 @@ PT_DEV uint32_t stack4_pop(const Stack4& s, uint32_t& sp, float best_t)
 {
   while (sp > 0u) {
     --sp;
-    const uint2 e = stack4_read(s, sp);
+    uint2 e = stack4_read(s, sp);
+    // (one 8-byte read: the compiler otherwise fetches the distance, compares, and only then fetches the reference — two
+    // dependent round trips per pop)
+    asm volatile("" : "+v"(e.x), "+v"(e.y));
     if (u_as_f(e.y) <= best_t) return e.x;
   }
   return PT_NONE;
