@@ -449,7 +449,7 @@ def main():
     is_headline = (W, H, spp, B, args.tessellate, args.aperture, args.atrium, proxy, args.fix_backslashes, os.path.basename(args.scene)) == \
                   (WIDTH, HEIGHT, SPP, BOUNCES, 1, None, False, False, False, "indoor.scene")
     if world == 1 and not args.no_extra and not force_gather and not proxy:
-        k2 = max(4, args.steps // 2)
+        k2 = max(4, args.steps)   # (as many steps as the headline: a whole-GPU launch opens every back-to-back sequence, short regions overweigh it)
         # (a) the same batched launch on one stream: issued back to back, and with the host waiting for every frame (latency)
         solo = Workload(P, torch, dist, hs, cube, W, H, spp, B, args.kernel, 1, False, not args.sequential, local_rank)
         sdt, s_ms = solo.run(k2, 2, args.settle_ms)
