@@ -398,6 +398,10 @@ PT_DEV ConstF as_constant(const float4* q) { return (ConstF)(uintptr_t)q; }
 // re-read from the kernel-argument segment where they are used — KParams is every kernel's first argument — behind a
 // compiler barrier, instead of living in SGPRs for the whole launch: the round loop is short of scalar registers
 // (43 SGPR spills = v_writelane / v_readlane in the loop before this, 8.10 -> 8.33 Gsamples/s for the camera alone).
+// PT_KARG reads KParams fields from the start of the kernel-argument segment WHATEVER object it is handed: every kernel whose
+// device functions use it must take the launch constants as its FIRST by-value argument — which is what this macro spells, so
+// that a kernel cannot be written otherwise by accident.
+#define PT_KERNEL_PARAMS const KParams p
 #if PT_CAM_FROM_KERNARG
 template <typename T>
 PT_DEV T karg_load(uint32_t byte_offset)
@@ -933,7 +937,7 @@ PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes,
 // One thread per pixel, as in the reference.  Workgroup = 256 threads = 4 waves; wave w owns
 // the 8x8 tile (w&1, w>>1) of a 16x16 block.  Lanes whose path ended idle until the wave is done.
 template <int KIND, bool LDS_RESIDENT, bool STATS, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, PT_TILE_WAVES_PER_EU) pt_megakernel(const KParams p)
+__global__ void __launch_bounds__(BLOCK, PT_TILE_WAVES_PER_EU) pt_megakernel(PT_KERNEL_PARAMS)
 {
   extern __shared__ float4 s_mem[];
   const float4* s_nodes;
@@ -964,7 +968,7 @@ __global__ void __launch_bounds__(BLOCK, PT_TILE_WAVES_PER_EU) pt_megakernel(con
 // pixels of the wave's tile queue (rank among idle lanes = mbcnt of the ballot), so the BVH walk
 // always runs with a nearly full exec mask and lanes at different bounce depths share it.
 template <int KIND, bool LDS_RESIDENT, bool STATS>
-__global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER_EU) pt_megakernel_persistent(const KParams p)
+__global__ void __launch_bounds__(PT_PERSISTENT_THREADS, PT_PERSISTENT_WAVES_PER_EU) pt_megakernel_persistent(PT_KERNEL_PARAMS)
 {
   extern __shared__ float4 s_mem[];
   const float4* s_nodes;
@@ -1447,10 +1451,9 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
 #define PT_RS_STAMPS 2
 #define PT_RS_BRUTE 3
 
-// KParams must stay this kernel's first by-value argument: PT_KARG reads its fields from the kernel-argument segment.
 template <bool LDS_RESIDENT, int VARIANT>
 __global__ void __launch_bounds__(LDS_RESIDENT ? PT_RS_THREADS : PT_RS4_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_EU : PT_RS4_WAVES_PER_EU)
-pt_megakernel_restart(const KParams p)
+pt_megakernel_restart(PT_KERNEL_PARAMS)
 {
   constexpr bool STATS = VARIANT == PT_RS_STATS;
   constexpr uint32_t THREADS = LDS_RESIDENT ? PT_RS_THREADS : PT_RS4_THREADS;
@@ -1648,7 +1651,7 @@ pt_megakernel_restart(const KParams p)
 //     wavefront-level restart keeps the box-test loop full with rays of the SAME bounce depth;
 //   * owners read their record back and shade; path state never leaves its lane.
 template <bool LDS_RESIDENT, bool STATS>
-__global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakernel_blockwise(const KParams p)
+__global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakernel_blockwise(PT_KERNEL_PARAMS)
 {
   constexpr uint32_t NW = PT_BW_THREADS / 64u; // waves per workgroup
   constexpr uint32_t NE = NW * 8u;             // entries of the [octant][wave] count table
@@ -1812,7 +1815,7 @@ __global__ void __launch_bounds__(PT_BW_THREADS, PT_BW_WAVES_PER_EU) pt_megakern
 // LDS operations of one wave execute in order, so "write rays, then publish" and "write result,
 // then count it" need no more than a compiler-level fence.
 template <bool LDS_RESIDENT, bool STATS>
-__global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakernel_split(const KParams p)
+__global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakernel_split(PT_KERNEL_PARAMS)
 {
   constexpr uint32_t NW = PT_SP_THREADS / 64u, NS = PT_SP_SHADERS, NT = NW - NS;
   static_assert(NS >= 1 && NT >= 1, "need at least one shader wave and one traverser wave");
@@ -2000,7 +2003,7 @@ __global__ void __launch_bounds__(256) pt_gamma_selftest(const float* T, uint32_
 // framebuffer in frame order — t = t * is_static + s_k for k = 0..count-1, exactly what `count`
 // consecutive launches do (raytrace.cu:255-256, is_static == 1) — then tonemap once with the last
 // frame number (the intermediate surfaces of frames 0..count-2 would be overwritten anyway).
-__global__ void __launch_bounds__(256) pt_resolve_kernel(const KParams p)
+__global__ void __launch_bounds__(256) pt_resolve_kernel(PT_KERNEL_PARAMS)
 {
   // the ticket heads of this launch are spent (the megakernel has finished: stream order): leave them zeroed for the
   // launch that gets this slot of the ring next, instead of a memset in front of every launch
@@ -2034,7 +2037,7 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel(const KParams p)
 
 // The same pass, four horizontally adjacent pixels per thread: the 48 bytes of a pixel group are three float4s in the
 // accumulator and in every sample plane, the four RGBA8 results one uint4.  Per-pixel arithmetic is unchanged.
-__global__ void __launch_bounds__(256) pt_resolve_kernel4(const KParams p)
+__global__ void __launch_bounds__(256) pt_resolve_kernel4(PT_KERNEL_PARAMS)
 {
   // the ticket heads of this launch are spent (the megakernel has finished: stream order): leave them zeroed for the
   // launch that gets this slot of the ring next, instead of a memset in front of every launch
@@ -2081,7 +2084,7 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel4(const KParams p)
 }
 
 // The same query through the four-wide walk: one wave per block, the stack entirely in (dynamic) LDS.
-__global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(const KParams p, const float* rays, uint32_t n, int4* out)
+__global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(PT_KERNEL_PARAMS, const float* rays, uint32_t n, int4* out)
 {
   extern __shared__ float4 s_mem[];
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
@@ -2110,7 +2113,7 @@ __global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(const KParams p,
 
 // Nearest-hit query on explicit rays (tests: BVH vs brute force on the device).
 template <int KIND>
-__global__ void __launch_bounds__(256) pt_trace_rays_kernel(const KParams p, const float* rays, uint32_t n, int4* out)
+__global__ void __launch_bounds__(256) pt_trace_rays_kernel(PT_KERNEL_PARAMS, const float* rays, uint32_t n, int4* out)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
