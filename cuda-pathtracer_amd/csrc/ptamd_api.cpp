@@ -504,10 +504,13 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
         if (!sc->mega_done[i]) PT_HIP(hipEventCreateWithFlags(&sc->mega_done[i], hipEventDisableTiming));
         if (!sc->resolved[i]) PT_HIP(hipEventCreateWithFlags(&sc->resolved[i], hipEventDisableTiming));
       }
-      // all three slabs grow together (allocating synchronises: it must not happen when a host that had waited for its
-      // frames starts to run ahead, nor inside a graph capture that follows an eager launch of the same configuration)
+      // The slabs a stream may use grow together: allocating synchronises, which must not happen when a host that had waited
+      // for its frames starts to run ahead, nor inside a graph capture that follows an eager launch of the same
+      // configuration.  The three pipelining slabs only for launches the library may pipeline (a caller that runs its own
+      // pipeline, machine_share > 1, never uses them: 4.8 GB per stream at 4K x 16 spp).
+      const bool may_pipeline = ctx->overlap && l->machine_share <= 1u && !stats;
       for (uint32_t i = 0; i < 4u; ++i) {
-        if (need <= sc->bytes[i] || (!ctx->overlap && i != 3u)) continue;
+        if (need <= sc->bytes[i] || (!may_pipeline && i != 3u)) continue;
         // launches of this stream (their megakernels possibly on the internal streams) are the only users of the old buffer
         PT_HIP(hipStreamSynchronize(stream));
         for (hipStream_t is : ctx->internal) if (is) PT_HIP(hipStreamSynchronize(is));
@@ -533,7 +536,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     hipStream_t mega_stream = stream;
     if (overlap) {
       // the megakernel touches nothing of the caller's: it may start before earlier work on the caller's stream has finished,
-      // as soon as the slab's previous reader (the resolve pass two launches back) is done
+      // as soon as the slab's previous reader (the resolve pass three launches back) is done
       mega_stream = ctx->internal[sc->flip++ & 1u];
       if (sc->resolved_valid[scratch_slab]) PT_HIP(hipStreamWaitEvent(mega_stream, sc->resolved[scratch_slab], 0));
     }
