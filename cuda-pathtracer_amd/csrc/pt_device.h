@@ -309,7 +309,7 @@ struct KParams {
   // pt_f2u(pt_powf(x, 1/2.2) * 255) reaches j, T[0] = 0, T[256] the smallest x whose value reaches 256 (from there on the
   // resolve pass evaluates pt_powf as before).  nullptr: no table, pt_powf everywhere.
   const float* gamma_table;
-  // wide walk (scenes that do not fit in LDS): 8 float4 per node (Bvh::nodes8, or Bvh::nodes4 in PT_WIDE8=0 builds), per-lane
+  // wide walk (scenes that do not fit in LDS): 8 float4 per node — Bvh::nodes4, or Bvh::nodes8 when `wide8` is set —, per-lane
   // stacks in LDS with a global continuation
   const float4* nodes4;
   uint32_t n_nodes4;
@@ -320,6 +320,7 @@ struct KParams {
   uint32_t treelet_nodes;   // the first nodes of nodes4 (top of the tree) are staged in LDS in front of the stacks
   uint2* stack_spill;
   uint32_t walk_min4;
+  uint32_t wide8;                 // `nodes4` holds the eight-wide quantised form: selects the instantiation that walks it (PTAMD_WIDE8 knob)
   uint32_t far_table[16];         // eight-wide walk: for ray octant o, byte c of the pair [2 o], [2 o + 1] = the slots visited after slot c
   uint32_t brute_walk;            // restart kernel: the launch wants the instantiation that tests every triangle record instead of walking the tree (far origin)
   unsigned long long* timeline;   // restart kernel: != nullptr selects the instantiation that records 4 time stamps per wave (ptamd_set_timeline)

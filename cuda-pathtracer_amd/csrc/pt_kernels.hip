@@ -1296,9 +1296,6 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
 // it selects the entry / exit plane arrays (no min / max per axis) and the visiting order: children sit in slots by direction
 // (bvh_builder.cpp), ascending (slot ^ octant) is front to back.  far[c] = the slots a ray of this octant reaches AFTER slot c
 // (one byte per slot, two dwords per ray, from KParams::far_table): a hit child's stack position is one popcount.
-#ifndef PT_WIDE8
-#define PT_WIDE8 0   /* 1: the eight-wide quantised nodes (A/B builds; the host side follows the same macro) */
-#endif
 
 struct Walk8 {
   uint32_t oct;   // bit a: the direction's sign bit along axis a
@@ -1373,16 +1370,16 @@ PT_DEV uint32_t walk8_visit(const float4* nodes8, const Stack4& stk, const Walk&
 }
 
 // One round of the wide walk for the lanes that call it (see traverse_round): cur == PT_NONE on return: finished.
-template <bool STATS>
+template <bool STATS, bool WIDE8 = false>
 PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4* tris, const Stack4& stk, f3 o, f3 d, Best& best, uint32_t& cur,
                             uint32_t& sp, uint32_t round_min, uint32_t round_div, uint32_t walk_min, bool small_det, Counters& cnt)
 {
   Walk w;
   walk_init(w, o, d, 1u);
   w.best = best;
-#if PT_WIDE8
-  const Walk8 x8 = walk8_init(p, d);
-#endif
+  Walk8 x8;
+  x8.oct = 0u; x8.far = make_uint2(0u, 0u);
+  if (WIDE8) x8 = walk8_init(p, d);
   const uint32_t n_start = (uint32_t)__popcll(__ballot(cur != PT_NONE));
   uint32_t t_eff = (n_start + round_div - 1u) / round_div;
   if (t_eff > round_min) t_eff = round_min;
@@ -1398,11 +1395,8 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
           cnt.nodes++;
           if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) cnt.wave_node_iters++;
         }
-#if PT_WIDE8
-        cur = walk8_visit<STATS>(nodes4, stk, w, x8, cur, sp);
-#else
-        cur = walk4_visit<STATS>(nodes4, stk, w, cur, sp);
-#endif
+        if (WIDE8) cur = walk8_visit<STATS>(nodes4, stk, w, x8, cur, sp);
+        else cur = walk4_visit<STATS>(nodes4, stk, w, cur, sp);
       }
       if (walkers < walk_min) break;
     }
@@ -1450,6 +1444,7 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
 #define PT_RS_STATS 1
 #define PT_RS_STAMPS 2
 #define PT_RS_BRUTE 3
+#define PT_RS_WIDE8 4   /* scenes that do not fit in LDS walked in the eight-wide quantised form (Bvh::nodes8) instead of the four-wide one */
 
 template <bool LDS_RESIDENT, int VARIANT>
 __global__ void __launch_bounds__(LDS_RESIDENT ? PT_RS_THREADS : PT_RS4_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_EU : PT_RS4_WAVES_PER_EU)
@@ -1603,7 +1598,7 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
         if (STATS) cnt.tris += p.n_bvh_tris;
         node = PT_END;
       } else if (WIDE) {
-        traverse_round4<STATS>(p, p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, p.small_det != 0u, cnt);
+        traverse_round4<STATS, VARIANT == PT_RS_WIDE8>(p, p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, p.small_det != 0u, cnt);
         node = cur == PT_NONE ? PT_END : 0u;
       } else {
         traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.walk_min, p.small_det != 0u, cnt);
@@ -2084,6 +2079,7 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel4(PT_KERNEL_PARAMS)
 }
 
 // The same query through the four-wide walk: one wave per block, the stack entirely in (dynamic) LDS.
+template <bool WIDE8>
 __global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(PT_KERNEL_PARAMS, const float* rays, uint32_t n, int4* out)
 {
   extern __shared__ float4 s_mem[];
@@ -2101,7 +2097,7 @@ __global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(PT_KERNEL_PARAMS
   Best best;
   best.t = PT_MAX_DIST; best.u = best.v = 0.f; best.idx = PT_END;
   uint32_t cur = (live && p.n_nodes4) ? 0u : PT_NONE, sp = 0u;
-  if (live) traverse_round4<false>(p, p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, p.small_det != 0u, cnt);
+  if (live) traverse_round4<false, WIDE8>(p, p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, p.small_det != 0u, cnt);
   if (!live) return;
   Nearest nr;
   nr.t = best.t; nr.u = best.u; nr.v = best.v; nr.idx = best.idx;
@@ -2206,6 +2202,7 @@ static const void* restart_entry(int variant)
     case PT_RS_STATS: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_STATS>);
     case PT_RS_STAMPS: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_STAMPS>);
     case PT_RS_BRUTE: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_BRUTE>);
+    case PT_RS_WIDE8: return reinterpret_cast<const void*>(pt_megakernel_restart<false, PT_RS_WIDE8>);   // (only ever a non-resident scene)
     default: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_PLAIN>);
   }
 }
@@ -2213,7 +2210,7 @@ static const void* restart_entry(int variant)
 // variant: instrumented build when counters are wanted, else the far-origin form, else the time-stamp form, else the shipped kernel
 static const void* restart_select(bool lds_resident, bool stats, const KParams* p = nullptr)
 {
-  const int variant = stats ? PT_RS_STATS : (p && p->brute_walk ? PT_RS_BRUTE : (p && p->timeline ? PT_RS_STAMPS : PT_RS_PLAIN));
+  const int variant = stats ? PT_RS_STATS : (p && p->brute_walk ? PT_RS_BRUTE : (p && p->timeline ? PT_RS_STAMPS : (p && p->wide8 && !lds_resident ? PT_RS_WIDE8 : PT_RS_PLAIN)));
   return lds_resident ? restart_entry<true>(variant) : restart_entry<false>(variant);
 }
 
@@ -2362,14 +2359,14 @@ hipError_t resolve_kernels()
     persistent_select(true, false), persistent_select(false, false), persistent_select(true, true), persistent_select(false, true),
     split_select(true, false), split_select(false, false), blockwise_select(true, false), blockwise_select(false, false),
     restart_entry<true>(PT_RS_PLAIN), restart_entry<false>(PT_RS_PLAIN), restart_entry<true>(PT_RS_STATS), restart_entry<false>(PT_RS_STATS),
-    restart_entry<true>(PT_RS_STAMPS), restart_entry<false>(PT_RS_STAMPS), restart_entry<true>(PT_RS_BRUTE), restart_entry<false>(PT_RS_BRUTE),
+    restart_entry<true>(PT_RS_STAMPS), restart_entry<false>(PT_RS_STAMPS), restart_entry<true>(PT_RS_BRUTE), restart_entry<false>(PT_RS_BRUTE), restart_entry<false>(PT_RS_WIDE8),
     reinterpret_cast<const void*>(pt_megakernel<1, true, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_megakernel<1, false, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_megakernel<2, true, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_megakernel<2, false, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_resolve_kernel), reinterpret_cast<const void*>(pt_resolve_kernel4),
     reinterpret_cast<const void*>(pt_trace_rays_kernel<1>), reinterpret_cast<const void*>(pt_trace_rays_kernel<2>),
-    reinterpret_cast<const void*>(pt_trace_rays_wide_kernel),
+    reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<false>), reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<true>),
   };
   for (const void* fn : fns) {
     hipFuncAttributes attr;
@@ -2386,10 +2383,12 @@ hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, 
   if (kind == 3) {   // four-wide walk; p.stack_lds_entries covers the whole stack (3 x depth of the wide tree)
     const size_t lds = (size_t)p.stack_lds_entries * 64u * sizeof(uint2);
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pt_trace_rays_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(p.wide8 ? reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<true>) : reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(pt_trace_rays_wide_kernel, dim3((n + 63u) / 64u), dim3(64), lds, stream, p, rays_dev, n, out_dev);
+    if (p.wide8) hipLaunchKernelGGL(pt_trace_rays_wide_kernel<true>, dim3((n + 63u) / 64u), dim3(64), lds, stream, p, rays_dev, n, out_dev);
+    else hipLaunchKernelGGL(pt_trace_rays_wide_kernel<false>, dim3((n + 63u) / 64u), dim3(64), lds, stream, p, rays_dev, n, out_dev);
     return hipGetLastError();
   }
   dim3 grid((n + 255u) / 256u);

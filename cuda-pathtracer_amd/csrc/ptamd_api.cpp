@@ -34,7 +34,9 @@ namespace {
 
 struct DeviceScene {
   float4* nodes = nullptr;
-  float4* nodes4 = nullptr;   // the wide form of the same tree (8 float4 per node: eight-wide quantised, or four-wide in PT_WIDE8=0 builds)
+  float4* nodes4 = nullptr;   // the four-wide form of the same tree (8 float4 per node)
+  float4* nodes8 = nullptr;   // ... and the eight-wide quantised form (8 float4 per node): walked instead when PTAMD_WIDE8=1 (tuning)
+  uint32_t n_nodes8 = 0, depth8 = 0;
   float4* tris_bvh = nullptr;
   float4* tris_brute = nullptr;
   float4* shade = nullptr;
@@ -104,6 +106,7 @@ struct ptamd_context {
   // a host that simply calls raytrace() again without synchronising (gpu_processor.cpp:365-386 does not).
   hipStream_t internal[2] = { nullptr, nullptr };
   bool overlap = true;                    // PTAMD_OVERLAP=0 (tuning): everything on the caller's stream
+  bool wide8 = false;                     // PTAMD_WIDE8=1 (tuning): big scenes walk the eight-wide quantised nodes (measured 8 % slower: DESIGN.md §4)
   unsigned long long* d_timeline = nullptr;   // ptamd_set_timeline: 4 time stamps per wave of the restart kernel
   uint32_t timeline_waves = 0;
   uint32_t default_kernel = PTAMD_KERNEL_BVH_RESTART; // what PTAMD_KERNEL_AUTO means
@@ -173,14 +176,11 @@ int upload(T*& dst, const void* src, size_t bytes)
 
 void free_scene(DeviceScene& s)
 {
-  void* ptrs[] = { s.nodes, s.nodes4, s.tris_bvh, s.tris_brute, s.shade, s.materials, s.lights, s.textures, s.texels };
+  void* ptrs[] = { s.nodes, s.nodes4, s.nodes8, s.tris_bvh, s.tris_brute, s.shade, s.materials, s.lights, s.textures, s.texels };
   for (void* q : ptrs) (void)hipFree(q);
   s = DeviceScene();
 }
 
-#ifndef PT_WIDE8
-#define PT_WIDE8 0   /* same macro as pt_kernels.hip: 1 = the eight-wide quantised nodes, 0 = the four-wide float nodes */
-#endif
 // KParams::far_table: children sit in slots by direction and a ray of octant o visits them in ascending (slot ^ o) order;
 // byte c of the entry of octant o = the slots visited AFTER slot c
 void fill_far_table(uint32_t t[16])
@@ -428,14 +428,17 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     // ([entry][lane], 512 bytes per entry and wave), the rest in a global slab.
     size_t launch_lds = lds;
     if (restart && !resident) {
-      const uint32_t need = (PT_WIDE8 ? 7u : 3u) * s.depth4 + 1u;   // a visit stacks all hit children but the nearest
+      // the eight-wide quantised form instead of the four-wide one (knob; not for the instrumented / time-stamp / far-origin instantiations)
+      const bool wide8 = ctx->wide8 && !stats && !p.brute_walk && !ctx->d_timeline && s.n_nodes8 != 0;
+      if (wide8) { p.nodes4 = s.nodes8; p.n_nodes4 = s.n_nodes8; p.wide8 = 1u; }
+      const uint32_t need = (wide8 ? 7u * s.depth8 : 3u * s.depth4) + 1u;   // a visit stacks all hit children but the nearest
       const uint32_t waves = restart_threads(false) / 64u;
       const uint32_t share = 160u * 1024u / restart_wide_blocks_per_cu() - 256u;   // LDS bytes of one resident workgroup
       // the top of the tree (breadth-first numbering: nodes 0..340 are its first five levels when full) goes to LDS too:
       // 512 nodes = 64 KB of the one workgroup's 160 KB, then 7 stack entries per lane
       // ... and the waves' pools of fresh paths (PT_POOL_LDS_BYTES each), behind the stacks
       const uint32_t pools = ctx->pool_in_lds ? waves * PT_POOL_LDS_BYTES : 0u;
-      uint32_t treelet = ctx->treelet_nodes < s.n_nodes4 ? ctx->treelet_nodes : s.n_nodes4;
+      uint32_t treelet = ctx->treelet_nodes < p.n_nodes4 ? ctx->treelet_nodes : p.n_nodes4;
       if (treelet * 128u + waves * 512u * 4u + pools > share) treelet = (share - pools - waves * 512u * 4u) / 128u;   // keep >= 4 stack entries
       uint32_t fit = (share - pools - treelet * 128u) / (waves * 512u);
       if (const char* ev = tuning_env("PTAMD_STACK_LDS")) { int v = std::atoi(ev); if (v >= 1 && (uint32_t)v <= fit) fit = (uint32_t)v; }   // tuning knob
@@ -673,6 +676,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
     ctx->walk_min4 = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
   }
   if (const char* e = tuning_env("PTAMD_SHORT_RCP")) ctx->short_rcp = std::atoi(e) != 0; // tuning knob
+  if (const char* e = tuning_env("PTAMD_WIDE8")) ctx->wide8 = std::atoi(e) != 0; // tuning knob
   if (const char* e = tuning_env("PTAMD_POOL_LDS")) ctx->pool_in_lds = std::atoi(e) != 0; // tuning knob
   if (const char* e = tuning_env("PTAMD_TREELET")) { // tuning knob
     int v = std::atoi(e);
@@ -799,15 +803,16 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   DeviceScene d;
   d.n_faces = sc->n_faces; d.n_lights = sc->n_lights; d.n_nodes = bvh.n_nodes; d.n_bvh_tris = bvh.n_tris;
   d.extent = bvh.extent; d.all_finite = bvh.all_finite; d.margin_floor = bvh.margin_floor;
-  // (d.nodes4 / n_nodes4 / depth4: the wide form the kernels walk — eight-wide unless built with PT_WIDE8=0)
-  d.n_nodes4 = PT_WIDE8 ? bvh.n_nodes8 : bvh.n_nodes4; d.depth4 = PT_WIDE8 ? bvh.depth8 : bvh.depth4;
+  d.n_nodes4 = bvh.n_nodes4; d.depth4 = bvh.depth4;
+  d.n_nodes8 = bvh.n_nodes8; d.depth8 = bvh.depth8;
   d.n_materials = sc->n_materials; d.n_textures = sc->n_textures;
   // device copy of the lights: the radius only ever enters as radius * radius (intersection.cuh:147) — the same binary32
   // product whoever forms it — so the table carries the square in its place and every sphere test saves the multiply
   std::vector<ptamd_light> dev_lights(sc->lights, sc->lights + sc->n_lights);
   for (ptamd_light& dl : dev_lights) dl.radius = dl.radius * dl.radius;
   if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
-      (rc = PT_WIDE8 ? upload(d.nodes4, bvh.nodes8.data(), bvh.nodes8.size() * 4) : upload(d.nodes4, bvh.nodes4.data(), bvh.nodes4.size() * 4)) ||
+      (rc = upload(d.nodes4, bvh.nodes4.data(), bvh.nodes4.size() * 4)) ||
+      (rc = upload(d.nodes8, bvh.nodes8.data(), bvh.nodes8.size() * 4)) ||
       (rc = upload(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4)) ||
       (rc = upload(d.tris_brute, brute.data(), brute.size() * 4)) ||
       (rc = upload(d.shade, shade.data(), shade.size() * 4)) ||
@@ -998,7 +1003,8 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4;
   fill_far_table(p.far_table);
   p.small_det = 0u;                           // caller-supplied directions need not be unit vectors
-  p.stack_lds_entries = (PT_WIDE8 ? 7u : 3u) * s.depth4 + 1u;   // PTAMD_KERNEL_BVH_RESTART: the wide walk, whole stack in LDS
+  p.stack_lds_entries = 3u * s.depth4 + 1u;   // PTAMD_KERNEL_BVH_RESTART: the wide walk, whole stack in LDS
+  if (ctx->wide8 && s.n_nodes8 != 0) { p.nodes4 = s.nodes8; p.n_nodes4 = s.n_nodes8; p.wide8 = 1u; p.stack_lds_entries = 7u * s.depth8 + 1u; }
   float* d_rays = nullptr;
   int4* d_out = nullptr;
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));

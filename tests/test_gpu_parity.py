@@ -389,6 +389,40 @@ def test_wide_walk_with_a_spilling_stack(P, O, gpu_ctx, monkeypatch):
     assert_same(acc, rgba, *ref, "wide walk, stack in LDS")
 
 
+def test_eight_wide_quantised_walk_on_the_device(P, O, monkeypatch):
+    """The eight-wide form of the tree (Bvh::nodes8: float origin, per-axis power-of-two scale, 8-bit planes, children in
+    direction slots) walked by the device — a tuning knob since it measured 8 % slower than the four-wide walk:
+    nearest-hit records == brute-force oracle, rendered frames == oracle, with the stack in LDS and mostly in the global
+    slab, and a batched launch == consecutive launches."""
+    import torch
+    monkeypatch.setenv("PTAMD_TUNING", "1")
+    monkeypatch.setenv("PTAMD_WIDE8", "1")
+    rng = np.random.default_rng(43)
+    with P.Context(0) as ctx:                       # (knobs are read when a context is created)
+        soup = make_scene(P, random_soup(rng, 3000, extent=3.0, size=0.25))
+        sid = ctx.upload_scene(soup)
+        rays = random_rays(rng, 20000)
+        rays[:40, 0] = 0.0
+        rays[40:80, 1:3] = -0.0                     # zeros of either sign: the octant comes from the sign bit
+        want = O.intersect(O.OracleScene.from_host_scene(soup, P.cubemap_from_color()), rays)
+        np.testing.assert_array_equal(ctx.trace_rays(sid, rays, P.KERNEL_BVH_RESTART), want)
+        assert (want[:, 0] == 1).sum() > 2000
+        hs = make_scene(P, random_soup(rng, 2500, extent=2.5, size=0.3), lights=[((0.0, 3.0, 1.0), (1, 1, 1), 6.0, 0.7)])
+        cube = synthetic_cubemap(rng, 4)
+        ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 96, 64, spp=2, bounces=4)
+        for stack_lds in (None, "2"):
+            if stack_lds:
+                monkeypatch.setenv("PTAMD_STACK_LDS", stack_lds)
+            acc, rgba = gpu_render(P, ctx, hs, cube, 96, 64, 2, 4, P.KERNEL_BVH_RESTART)
+            assert_same(acc, rgba, *ref, f"eight-wide walk, PTAMD_STACK_LDS={stack_lds}")
+        monkeypatch.delenv("PTAMD_STACK_LDS")
+        ids = (ctx.upload_scene(hs), ctx.upload_cubemap(cube))
+        fr = P.FrameRenderer(ctx, *ids, hs.camera_struct(), 96, 64)
+        fr.render(spp=2, bounces=4, batched=True)
+        torch.cuda.synchronize()
+        assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref, "eight-wide walk, batched")
+
+
 def test_scene_that_fills_the_lds_share_keeps_its_pools_in_global_memory(P, O, gpu_ctx):
     """An LDS-resident scene of 53-64 KB leaves no room for the restart kernel's path pools next to two scene copies: they
     go to the global slab instead (ptamd_api.cpp); same pixels either way."""
