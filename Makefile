@@ -58,4 +58,14 @@ endif
 clean:
 	rm -f $(LIB) $(ORACLE) $(REFLIB) $(GLLIB)
 
-.PHONY: all lib oracle oracle-ref gl clean
+.PHONY: all lib oracle oracle-ref gl clean san
+
+# sanitizer harness of the HOST half (parsers, decoders, builder): g++ with ASan + UBSan over the same sources the library is
+# built from; run by tests/test_sanitizers.py (GPU sanitizers are not available: the device half is covered by the parity suite)
+SAN := build/host_san
+HOST_SRCS := $(PKG)/host/scene_loader.cpp $(PKG)/host/bvh_builder.cpp $(PKG)/host/image_decode.cpp $(PKG)/host/image_png.cpp $(PKG)/host/image_resize.cpp
+san: $(SAN)
+$(SAN): tests/san/host_san.cpp $(HOST_SRCS) include/ptamd.h $(PKG)/host/ptamd_internal.h
+	@mkdir -p build
+	g++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -ffp-contract=off -Wall -Wextra -Wno-unused-parameter \
+	    -Iinclude -I$(PKG)/host -o $@ tests/san/host_san.cpp $(HOST_SRCS) -lpthread
