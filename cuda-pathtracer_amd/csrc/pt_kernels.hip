@@ -234,13 +234,13 @@ static_assert(PT_TILE_WAVES_PER_EU <= 6 && PT_PERSISTENT_WAVES_PER_EU <= 6 && PT
 PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w, uint32_t& leaf_first, uint32_t& leaf_count, uint32_t walk_min)
 {
   // COMPACT LDS nodes (stage_scene), two arrays of 32-byte records, N nodes each:
-  //   boxes[n] at lds_nodes + 32 n:          dwords 0..3 lo.xyz hi.x | 4..5 hi.yz | 6 leaf word
+  //   boxes[n] at lds_nodes + 32 n:          dwords 0..3 centre.xyz half.x | 4..5 half.yz | 6 leaf word
   //   links[n] at lds_nodes + 32 N + 32 n:   one word per ray octant
   // links[n][o] = hit code | miss code << 16, 16 bits each:
   //   < 0x8000  LDS byte address of the box to test next          0xFFFF  end of the walk
   //   0x8000 | (addr >> 1)  "park at the leaf whose box is at addr" (only ever a hit code, of the leaf itself)
   // so one v_cndmask with sub-dword selects yields the next state and one unsigned compare says whether to keep
-  // walking: 21 VALU, 4 SALU and 8 LDS cycles per iteration (the plain layout took 33 / 20 / 10).  A lane that parks
+  // walking: 17 VALU, 4 SALU and 8 LDS cycles per iteration (the plain layout took 33 / 20 / 10; lo / hi boxes 20 VALU).  A lane that parks
   // stops executing; its leaf word and miss link are fetched once, after the loop.
   unsigned long long save;
   uint32_t walkers;   // lanes still in the box loop; the loop runs while walkers >= walk_min (walk_min 1: until none is left)
@@ -254,22 +254,21 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
       "s_cbranch_execz 2f\n\t"
       "1:\n\t"
       "v_add_u32 v74, %[st], %[lnk]\n\t"
-      "ds_read_b128 v[64:67], %[st]\n\t"              // lo.xyz, hi.x
-      "ds_read_b64 v[68:69], %[st] offset:16\n\t"     // hi.yz
+      "ds_read_b128 v[64:67], %[st]\n\t"              // centre.xyz, half.x
+      "ds_read_b64 v[68:69], %[st] offset:16\n\t"     // half.yz
       "ds_read_b32 v72, v74\n\t"                       // hit | miss << 16 for this ray's octant
       "s_waitcnt lgkmcnt(1)\n\t"
+      // slab distances from the box's centre and half extent: t(centre) -+ half * |1/d| are the entry and exit distances of
+      // an axis whatever the sign of d — nine fma and no min / max per axis (the lo / hi form took six fma and six min / max)
       "v_fma_f32 v64, v64, %[ix], %[nx]\n\t"
-      "v_fma_f32 v67, v67, %[ix], %[nx]\n\t"
       "v_fma_f32 v65, v65, %[iy], %[ny]\n\t"
-      "v_fma_f32 v68, v68, %[iy], %[ny]\n\t"
       "v_fma_f32 v66, v66, %[iz], %[nz]\n\t"
-      "v_fma_f32 v69, v69, %[iz], %[nz]\n\t"
-      "v_min_f32 v74, v64, v67\n\t"
-      "v_max_f32 v64, v64, v67\n\t"
-      "v_min_f32 v67, v65, v68\n\t"
-      "v_max_f32 v65, v65, v68\n\t"
-      "v_min_f32 v68, v66, v69\n\t"
-      "v_max_f32 v66, v66, v69\n\t"
+      "v_fma_f32 v74, -v67, |%[ix]|, v64\n\t"
+      "v_fma_f32 v64, v67, |%[ix]|, v64\n\t"
+      "v_fma_f32 v67, -v68, |%[iy]|, v65\n\t"
+      "v_fma_f32 v65, v68, |%[iy]|, v65\n\t"
+      "v_fma_f32 v68, -v69, |%[iz]|, v66\n\t"
+      "v_fma_f32 v66, v69, |%[iz]|, v66\n\t"
       "v_max3_f32 v74, v74, v67, v68\n\t"              // tnear
       "v_min3_f32 v64, v64, v65, v66\n\t"              // tfar
       // hit <=> tnear <= tfar && 0 <= tfar && tnear <= best  <=>  max(tnear, 0) <= min(tfar, best)   (best >= 0)
@@ -876,7 +875,7 @@ PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t sampl
 }
 
 // COMPACT (the asm box loop's layout, see walk_to_leaf_lds): the 64-byte node is split into a 32-byte box record
-// (lo.xyz hi.x | hi.yz | leaf word) and a 32-byte link record in a second array; the eight per-octant miss links (node
+// (centre.xyz half.x | half.yz | leaf word) and a 32-byte link record in a second array; the eight per-octant miss links (node
 // indices) become eight words "hit code | miss code << 16": a code below 0x8000 is the LDS byte address of the next
 // box (hit: the child a ray of that octant visits first — left = node + 1, or the right child when the ray runs against
 // the split axis; miss: the old link), 0xFFFF ends the walk, and a leaf's hit code is 0x8000 | (its own address >> 1).
@@ -913,8 +912,17 @@ PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes,
             word[o] = ha | (ma << 16);
           }
           float4* links = s_mem + p.n_nodes * 2u;
-          s_mem[i * 2 + 0] = make_float4(q0.x, q0.y, q0.z, q1.x);
-          s_mem[i * 2 + 1] = make_float4(q1.y, q1.z, q0.w, 0.0f);
+          // the box as centre and half extent (the loop then needs no min / max per axis: walk_to_leaf_lds_state).  The half
+          // extent is rounded up — [c - h, c + h] contains [lo, hi] —; a box that is not finite becomes "everything".
+          float c[3], h[3];
+          const float lo[3] = { q0.x, q0.y, q0.z }, hi[3] = { q1.x, q1.y, q1.z };
+          for (int a = 0; a < 3; ++a) {
+            c[a] = 0.5f * lo[a] + 0.5f * hi[a];
+            h[a] = __builtin_fmaxf(hi[a] - c[a], c[a] - lo[a]) * 1.00000024f;   // (1 + 2^-22) covers the subtraction's half ulp
+            if (!(__builtin_fabsf(lo[a]) <= 3.0e38f && __builtin_fabsf(hi[a]) <= 3.0e38f)) { c[a] = 0.0f; h[a] = 3.0e38f; }
+          }
+          s_mem[i * 2 + 0] = make_float4(c[0], c[1], c[2], h[0]);
+          s_mem[i * 2 + 1] = make_float4(h[1], h[2], q0.w, 0.0f);
           links[i * 2 + 0] = make_float4(u_as_f(word[0]), u_as_f(word[1]), u_as_f(word[2]), u_as_f(word[3]));
           links[i * 2 + 1] = make_float4(u_as_f(word[4]), u_as_f(word[5]), u_as_f(word[6]), u_as_f(word[7]));
         }
