@@ -1259,16 +1259,18 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
   uint32_t hit = 0;
 #define PT_CHILD(c, X)                                                                                                   \
   {                                                                                                                      \
-    const float t0x = __builtin_fmaf(lx.X, w.inv.x, w.noi.x), t1x = __builtin_fmaf(hx.X, w.inv.x, w.noi.x);               \
-    const float t0y = __builtin_fmaf(ly.X, w.inv.y, w.noi.y), t1y = __builtin_fmaf(hy.X, w.inv.y, w.noi.y);               \
-    const float t0z = __builtin_fmaf(lz.X, w.inv.z, w.noi.z), t1z = __builtin_fmaf(hz.X, w.inv.z, w.noi.z);               \
-    const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),            \
-                                        __builtin_fminf(t0z, t1z));                                                      \
-    const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),             \
-                                       __builtin_fmaxf(t0z, t1z));                                                       \
+    /* (lx .. lz hold the child boxes' centres, hx .. hz their half extents: entry / exit = t(centre) -+ half * |1/d|) */  \
+    const float tcx = __builtin_fmaf(lx.X, w.inv.x, w.noi.x), tcy = __builtin_fmaf(ly.X, w.inv.y, w.noi.y),               \
+                tcz = __builtin_fmaf(lz.X, w.inv.z, w.noi.z);                                                            \
+    const float n0x = __builtin_fmaf(-hx.X, aix, tcx), f0x = __builtin_fmaf(hx.X, aix, tcx);                              \
+    const float n0y = __builtin_fmaf(-hy.X, aiy, tcy), f0y = __builtin_fmaf(hy.X, aiy, tcy);                              \
+    const float n0z = __builtin_fmaf(-hz.X, aiz, tcz), f0z = __builtin_fmaf(hz.X, aiz, tcz);                              \
+    const float tnear = __builtin_fmaxf(__builtin_fmaxf(n0x, n0y), n0z);                                                 \
+    const float tfar = __builtin_fminf(__builtin_fminf(f0x, f0y), f0z);                                                  \
     tn[c] = __builtin_fmaxf(tnear, 0.0f);                                                                                \
     if (tn[c] <= __builtin_fminf(tfar, w.best.t)) hit |= 1u << c;                                                        \
   }
+  const float aix = __builtin_fabsf(w.inv.x), aiy = __builtin_fabsf(w.inv.y), aiz = __builtin_fabsf(w.inv.z);
   PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w)
 #undef PT_CHILD
   if (hit == 0u) return stack4_pop(stk, sp, w.best.t);

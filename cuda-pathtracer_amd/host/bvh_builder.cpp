@@ -457,15 +457,21 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
         if (wide[w].child[c] < 0) {
           // empty slot: a point box far beyond MAX_DIST (no ray reaches it: its slab distances are +-huge, never within
           // [0, best <= 1e5]), reference 0xFFFFFFFF
-          for (int a = 0; a < 3; ++a) { q[a * 4 + c] = 3.0e38f; q[12 + a * 4 + c] = 3.0e38f; }
+          for (int a = 0; a < 3; ++a) { q[a * 4 + c] = 3.0e38f; q[12 + a * 4 + c] = 0.0f; }   // (centre, half extent)
           q[24 + c] = u2f(0xFFFFFFFFu);
           continue;
         }
         const BuildNode& cn = b.nodes[(size_t)wide[w].child[c]];
         for (int a = 0; a < 3; ++a) {
           const float lo = cn.box.lo[a], hi = cn.box.hi[a];
-          q[a * 4 + c] = lo - (margin + origin_margin + std::fabs(lo) * 1e-6f);
-          q[12 + a * 4 + c] = hi + (margin + origin_margin + std::fabs(hi) * 1e-6f);
+          // stored as centre and half extent (the walk then needs no min / max per axis: t(centre) -+ half * |1/d|); the half extent
+          // is rounded up, so [centre - half, centre + half] contains the inflated box; a box that is not finite becomes "everything"
+          const float blo = lo - (margin + origin_margin + std::fabs(lo) * 1e-6f), bhi = hi + (margin + origin_margin + std::fabs(hi) * 1e-6f);
+          float ctr = 0.5f * blo + 0.5f * bhi;
+          float half = std::max(bhi - ctr, ctr - blo) * 1.00000024f;
+          if (!(std::fabs(blo) <= 3.0e38f && std::fabs(bhi) <= 3.0e38f)) { ctr = 0.0f; half = 3.0e38f; }
+          q[a * 4 + c] = ctr;
+          q[12 + a * 4 + c] = half;
         }
         uint32_t ref;
         if (cn.left < 0) {
@@ -782,9 +788,9 @@ void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], 
     for (int c = 0; c < 4; ++c) {
       float tnear = -std::numeric_limits<float>::infinity(), tfar = std::numeric_limits<float>::infinity();
       for (int a = 0; a < 3; ++a) {
-        const float t0 = std::fma(q[a * 4 + c], inv[a], noi[a]), t1 = std::fma(q[12 + a * 4 + c], inv[a], noi[a]);
-        tnear = std::max(tnear, std::min(t0, t1));
-        tfar = std::min(tfar, std::max(t0, t1));
+        const float tc = std::fma(q[a * 4 + c], inv[a], noi[a]), ai = std::fabs(inv[a]);
+        tnear = std::max(tnear, std::fma(-q[12 + a * 4 + c], ai, tc));
+        tfar = std::min(tfar, std::fma(q[12 + a * 4 + c], ai, tc));
       }
       tn[c] = std::max(tnear, 0.0f);
       if (tn[c] <= std::min(tfar, best_t)) hit |= 1u << c;

@@ -72,7 +72,8 @@ struct Bvh {
   uint32_t n_tris = 0;           // triangle records (>= faces when references were split)
   // The same tree with four children per node, for scenes walked from L2/HBM with a per-lane stack (one 128-byte line
   // per node visit instead of one dependent 64-byte load per box test).  node record = 32 floats = 8 x float4:
-  //   q0..q2 = lo.x[4], lo.y[4], lo.z[4]     q3..q5 = hi.x[4], hi.y[4], hi.z[4]      (child boxes, one lane per child)
+  //   q0..q2 = centre.x[4], .y[4], .z[4]     q3..q5 = half extent .x[4], .y[4], .z[4]  (child boxes, one lane per child;
+  //            slab distances of an axis = t(centre) -+ half * |1/d|: no min / max per axis)
   //   q6     = reference[4]: 0xFFFFFFFF empty | node index | 0x80000000 | count << 24 | first triangle (leaf)
   //   q7     = 8 halfwords, one per ray octant: nibble c = the children that octant visits AFTER child c
   // Nodes are numbered breadth-first (node 0 = root).  Leaves point into `tris`.
