@@ -418,7 +418,9 @@ def test_eight_wide_quantised_walk_on_the_device(P, O, monkeypatch):
         monkeypatch.delenv("PTAMD_STACK_LDS")
         ids = (ctx.upload_scene(hs), ctx.upload_cubemap(cube))
         fr = P.FrameRenderer(ctx, *ids, hs.camera_struct(), 96, 64)
-        fr.render(spp=2, bounces=4, batched=True)
+        # (the batched launch names the restart kernel itself: PTAMD_DEFAULT_KERNEL, which only stands behind PTAMD_KERNEL_AUTO,
+        # may be pinned to a kernel that cannot batch — scripts/gpu_knobtest.sh)
+        fr.render(spp=2, bounces=4, kernel=P.KERNEL_BVH_RESTART, batched=True)
         torch.cuda.synchronize()
         assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref, "eight-wide walk, batched")
 
