@@ -143,7 +143,11 @@ struct Walk {
   uint32_t idle_unstarted, idle_finished, idle_parked;
 };
 
-PT_DEV void walk_init(Walk& w, f3 o, f3 d, uint32_t n_nodes)
+// Slab distances of the hand-scheduled LDS box loop are in units of 2^17 (an exact scaling): MAX_DIST = 1e5 then lies below 1, and
+// the lower clamp of a box's entry distance at 0 is the clamp modifier of one of the loop's fma — one instruction less per iteration.
+#define PT_T_SCALE 7.62939453125e-06f   /* 2^-17 */
+// asm_scaled: the walk is going to run through walk_to_leaf_lds_state (which expects inv / noi in those units)
+PT_DEV void walk_init(Walk& w, f3 o, f3 d, uint32_t n_nodes, bool asm_scaled = false)
 {
   w.o = o; w.d = d;
   w.oct = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
@@ -153,7 +157,8 @@ PT_DEV void walk_init(Walk& w, f3 o, f3 d, uint32_t n_nodes)
   const float dx = __builtin_fabsf(d.x) < tiny ? __builtin_copysignf(tiny, d.x) : d.x;
   const float dy = __builtin_fabsf(d.y) < tiny ? __builtin_copysignf(tiny, d.y) : d.y;
   const float dz = __builtin_fabsf(d.z) < tiny ? __builtin_copysignf(tiny, d.z) : d.z;
-  w.inv = mk3(__builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));
+  const float ts = asm_scaled ? PT_T_SCALE : 1.0f;
+  w.inv = mk3(__builtin_amdgcn_rcpf(dx) * ts, __builtin_amdgcn_rcpf(dy) * ts, __builtin_amdgcn_rcpf(dz) * ts);
   w.noi = mk3(-(o.x * w.inv.x), -(o.y * w.inv.y), -(o.z * w.inv.z));
   w.link_off = 8u + w.oct;
   w.n_nodes = n_nodes;
@@ -240,7 +245,7 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
   //   < 0x8000  LDS byte address of the box to test next          0xFFFF  end of the walk
   //   0x8000 | (addr >> 1)  "park at the leaf whose box is at addr" (only ever a hit code, of the leaf itself)
   // so one v_cndmask with sub-dword selects yields the next state and one unsigned compare says whether to keep
-  // walking: 17 VALU, 4 SALU and 8 LDS cycles per iteration (the plain layout took 33 / 20 / 10; lo / hi boxes 20 VALU).  A lane that parks
+  // walking: 16 VALU, 4 SALU and 8 LDS cycles per iteration (the plain layout took 33 / 20 / 10; lo / hi boxes 20 VALU).  A lane that parks
   // stops executing; its leaf word and miss link are fetched once, after the loop.
   unsigned long long save;
   uint32_t walkers;   // lanes still in the box loop; the loop runs while walkers >= walk_min (walk_min 1: until none is left)
@@ -267,12 +272,13 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
       "v_fma_f32 v64, v67, |%[ix]|, v64\n\t"
       "v_fma_f32 v67, -v68, |%[iy]|, v65\n\t"
       "v_fma_f32 v65, v68, |%[iy]|, v65\n\t"
-      "v_fma_f32 v68, -v69, |%[iz]|, v66\n\t"
+      "v_fma_f32 v68, -v69, |%[iz]|, v66 clamp\n\t"   // max(entry z, 0); the upper clamp at 1 = 2^17 lies beyond MAX_DIST
       "v_fma_f32 v66, v69, |%[iz]|, v66\n\t"
       "v_max3_f32 v74, v74, v67, v68\n\t"              // tnear
       "v_min3_f32 v64, v64, v65, v66\n\t"              // tfar
-      // hit <=> tnear <= tfar && 0 <= tfar && tnear <= best  <=>  max(tnear, 0) <= min(tfar, best)   (best >= 0)
-      "v_max_f32 v74, 0, v74\n\t"
+      // hit <=> tnear <= tfar && 0 <= tfar && tnear <= best  <=>  max(tnear, 0) <= min(tfar, best)   (best >= 0);
+      // the max with 0 came with the z entry distance's clamp (a box entered beyond 2^17 reads as entered AT 2^17: it can only
+      // pass while no hit is known, and then it is one visit too many, never one too few)
       "v_min_f32 v64, v64, %[best]\n\t"
       "v_cmp_le_f32 vcc, v74, v64\n\t"                 // box hit
       "s_waitcnt lgkmcnt(0)\n\t"
@@ -290,7 +296,7 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
 #endif
       : [st] "+v"(state), [save] "=&s"(save), [walkers] "=&s"(walkers)
       : [wmin] "s"(walk_min), [lnk] "v"(lnk), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
-        [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t)
+        [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t * PT_T_SCALE)
       : "v64", "v65", "v66", "v67", "v68", "v69", "v72", "v74", "vcc", "scc", "memory");
   leaf_first = 0u;
   leaf_count = 0u;
@@ -340,7 +346,7 @@ PT_DEV void traverse_bvh(const float4* nodes, const float4* tris, uint32_t n_nod
                          uint32_t& wave_tri_iters, uint32_t* idle3)
 {
   Walk w;
-  walk_init(w, o, d, n_nodes);
+  walk_init(w, o, d, n_nodes, NODES_IN_LDS && !STATS && PT_ASM_WALK);
   if (STATS) w.alive = (uint32_t)__popcll(__ballot(1));
   // LDS byte address of the node table (low 32 bits of the flat address of an LDS object)
   const uint32_t lds_nodes = (uint32_t)(uintptr_t)nodes;
@@ -1137,7 +1143,7 @@ PT_DEV void traverse_round(const float4* nodes, const float4* tris, uint32_t n_n
                            uint32_t round_min, uint32_t round_div, uint32_t walk_min, bool small_det, Counters& cnt)
 {
   Walk w;
-  walk_init(w, o, d, n_nodes);
+  walk_init(w, o, d, n_nodes, NODES_IN_LDS && !STATS && PT_ASM_WALK);
   w.best = best;
   w.node = node;
   const uint32_t n_start = (uint32_t)__popcll(__ballot(node != PT_END));
@@ -1940,7 +1946,7 @@ __global__ void __launch_bounds__(PT_SP_THREADS, PT_SP_WAVES_PER_EU) pt_megakern
           if (!have && rank < got) {
             const uint32_t r = base + rank;
             const float4 ra = rays[(b * 64u + r) * 2u + 0u], rb = rays[(b * 64u + r) * 2u + 1u];
-            walk_init(w, mk3(ra.w, rb.x, rb.y), mk3(ra.x, ra.y, ra.z), p.n_nodes);
+            walk_init(w, mk3(ra.w, rb.x, rb.y), mk3(ra.x, ra.y, ra.z), p.n_nodes, LDS_RESIDENT && !STATS && PT_ASM_WALK);
             have = true;
             my_slot = (b << 8) | r;
           }
