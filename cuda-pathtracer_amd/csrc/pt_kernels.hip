@@ -225,13 +225,13 @@ PT_DEV void walk_to_leaf(const float4* nodes, Walk& w, uint32_t& leaf_first, uin
 // carries ~20 SALU exec-mask instructions per iteration (two exits, phi merges of masks) next to
 // ~35 VALU, and the rocprofv3 counters show 39 % of wave time stalled at issue.  This version
 // keeps one exec update per iteration: lanes leave the loop by clearing their exec bit when they
-// reach a leaf they hit or run off the tree.  v64..v69, v72 and v74 are scratch (clobbered); masks live in
+// reach a leaf they hit or run off the tree.  v64..v69 and v74 are scratch (clobbered); masks live in
 // compiler-allocated SGPR pairs.  Hazards: a VALU that reads an SGPR mask written by a VALU
 // compare needs 2 wait states (s_nop 1), exactly as hipcc pads it; SALU consumers are interlocked.
 // `state` is the walk's position in the loop's own terms (below): the LDS address of the next box, or 0xFFFF when the walk is
 // over; it stays in that form between the box phases of a round (traverse_round) — converting it to a node index and
 // back costs four VALU per phase.
-// The loop names its scratch registers (v64..v69, v72, v74: a ds_read_b128 needs four consecutive ones, which an inline-asm operand
+// The loop names its scratch registers (v64..v69, v74: a ds_read_b128 needs four consecutive ones, which an inline-asm operand
 // cannot express dword by dword); they are in the clobber list, so the allocator keeps everything else out of them.  They must exist
 // in every kernel that inlines this loop: 75 VGPRs at least, i.e. at most 6 waves per SIMD (512 / 6 = 85) — checked here at build time.
 static_assert(PT_TILE_WAVES_PER_EU <= 6 && PT_PERSISTENT_WAVES_PER_EU <= 6 && PT_RS_WAVES_PER_EU <= 6 && PT_SP_WAVES_PER_EU <= 6,
@@ -243,11 +243,12 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
   //   links[n] at lds_nodes + 32 N + 32 n:   one word per ray octant
   // links[n][o] = hit code | miss code << 16, 16 bits each:
   //   < 0x8000  LDS byte address of the box to test next          0xFFFF  end of the walk
-  //   0x8000 | (addr >> 1)  "park at the leaf whose box is at addr" (only ever a hit code, of the leaf itself)
+  //   0x8000 | count << 11 | first   "park: test these triangle records" (only ever a hit code, of the leaf itself)
   // so one v_cndmask with sub-dword selects yields the next state and one unsigned compare says whether to keep
   // walking: 16 VALU, 4 SALU and 8 LDS cycles per iteration (the plain layout took 33 / 20 / 10; lo / hi boxes 20 VALU).  A lane that parks
-  // stops executing; its leaf word and miss link are fetched once, after the loop.
+  // stops executing: the link word it read last is its leaf's, whose upper half says where the walk goes on after the tests.
   unsigned long long save;
+  uint32_t link_word; // the link word a lane read last (a lane that parks read its leaf's)
   uint32_t walkers;   // lanes still in the box loop; the loop runs while walkers >= walk_min (walk_min 1: until none is left)
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
@@ -261,7 +262,7 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
       "v_add_u32 v74, %[st], %[lnk]\n\t"
       "ds_read_b128 v[64:67], %[st]\n\t"              // centre.xyz, half.x
       "ds_read_b64 v[68:69], %[st] offset:16\n\t"     // half.yz
-      "ds_read_b32 v72, v74\n\t"                       // hit | miss << 16 for this ray's octant
+      "ds_read_b32 %[lw], v74\n\t"                     // hit | miss << 16 for this ray's octant
       "s_waitcnt lgkmcnt(1)\n\t"
       // slab distances from the box's centre and half extent: t(centre) -+ half * |1/d| are the entry and exit distances of
       // an axis whatever the sign of d — nine fma and no min / max per axis (the lo / hi form took six fma and six min / max)
@@ -283,7 +284,7 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
       "v_cmp_le_f32 vcc, v74, v64\n\t"                 // box hit
       "s_waitcnt lgkmcnt(0)\n\t"
       "s_nop 0\n\t"                                    // a VALU read of VCC needs 2 wait states after the VALU compare that wrote it
-      "v_cndmask_b32_sdwa %[st], v72, v72, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+      "v_cndmask_b32_sdwa %[st], %[lw], %[lw], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
       "v_cmp_gt_u32 vcc, 0x8000, %[st]\n\t"            // a node address: keep walking (else parked at a leaf, or done)
       "s_and_b64 exec, exec, vcc\n\t"
       "s_bcnt1_i32_b64 %[walkers], exec\n\t"
@@ -294,19 +295,16 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
 #ifdef PT_WALK_PRIO
       "s_setprio 0\n\t"
 #endif
-      : [st] "+v"(state), [save] "=&s"(save), [walkers] "=&s"(walkers)
+      : [st] "+v"(state), [lw] "=&v"(link_word), [save] "=&s"(save), [walkers] "=&s"(walkers)
       : [wmin] "s"(walk_min), [lnk] "v"(lnk), [ix] "v"(w.inv.x), [iy] "v"(w.inv.y), [iz] "v"(w.inv.z),
         [nx] "v"(w.noi.x), [ny] "v"(w.noi.y), [nz] "v"(w.noi.z), [best] "v"(w.best.t * PT_T_SCALE)
-      : "v64", "v65", "v66", "v67", "v68", "v69", "v72", "v74", "vcc", "scc", "memory");
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v74", "vcc", "scc", "memory");
   leaf_first = 0u;
   leaf_count = 0u;
-  if (state >= 0x8000u && state != 0xFFFFu) {               // parked: 0x8000 | (address of the leaf's node >> 1)
-    typedef const __attribute__((address_space(3))) uint32_t* LdsU32;
-    const uint32_t leaf_addr = (state & 0x7FFFu) << 1;
-    const uint32_t info = *(LdsU32)(uintptr_t)(leaf_addr + 24u);
-    state = *(LdsU32)(uintptr_t)(leaf_addr + lnk) >> 16;    // the leaf's miss code: where the walk goes on after the tests
-    leaf_first = info & 0xFFFFFFu;
-    leaf_count = info >> 24;
+  if (state >= 0x8000u && state != 0xFFFFu) {               // parked: 0x8000 | count << 11 | first triangle record
+    leaf_first = state & 0x7FFu;
+    leaf_count = (state >> 11) & 0xFu;
+    state = link_word >> 16;                                // the leaf's miss code: where the walk goes on after the tests
   }
 }
 
@@ -884,7 +882,7 @@ PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t sampl
 // (centre.xyz half.x | half.yz | leaf word) and a 32-byte link record in a second array; the eight per-octant miss links (node
 // indices) become eight words "hit code | miss code << 16": a code below 0x8000 is the LDS byte address of the next
 // box (hit: the child a ray of that octant visits first — left = node + 1, or the right child when the ray runs against
-// the split axis; miss: the old link), 0xFFFF ends the walk, and a leaf's hit code is 0x8000 | (its own address >> 1).
+// the split axis; miss: the old link), 0xFFFF ends the walk, and a leaf's hit code is 0x8000 | count << 11 | first triangle record.
 // Box addresses must stay below 0x8000: 32 bytes per node, nodes first in LDS, so up to ~900 nodes — more than an
 // LDS-resident scene can have (64 bytes of links + boxes and >= 48 bytes of triangles per node pair in 64 KB); the
 // host checks it (ptamd_api.cpp: kCompactMaxNodes) and walks bigger trees from global memory.
@@ -901,19 +899,20 @@ PT_DEV void stage_scene(const KParams& p, float4* s_mem, const float4*& s_nodes,
         const uint32_t base = (uint32_t)(uintptr_t)s_mem;
         // box addresses are 15-bit codes: the host only launches this layout for <= kCompactMaxNodes nodes and the
         // kernels keep no static LDS in front of s_mem; should either ever change, stop here rather than walk garbage
-        if (base + p.n_nodes * 32u > 0x8000u) __builtin_trap();
+        // ... and a leaf's hit code holds its triangle range: count (<= 15) << 11 | first record (the host launches this layout
+        // for at most kCompactMaxTris records, so that no code collides with 0xFFFF)
+        if (base + p.n_nodes * 32u > 0x8000u || p.n_bvh_tris > 2047u) __builtin_trap();
         for (uint32_t i = threadIdx.x; i < p.n_nodes; i += blockDim.x) {
           const float4 q0 = p.nodes[i * 4 + 0], q1 = p.nodes[i * 4 + 1];
           const uint4 m0 = *reinterpret_cast<const uint4*>(p.nodes + i * 4 + 2), m1 = *reinterpret_cast<const uint4*>(p.nodes + i * 4 + 3);
           const uint32_t miss[8] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w };
           const uint32_t child = f_as_u(q1.w), right = child & 0x3FFFFFFFu, axis = child >> 30;
           const bool leaf = (f_as_u(q0.w) >> 24) != 0u;
-          const uint32_t self = base + i * 32u;
           uint32_t word[8];
           for (uint32_t o = 0; o < 8; ++o) {
             const uint32_t down = ((o >> axis) & 1u) ? right : i + 1u;
             // hit code: a leaf parks at itself; an interior node sends the ray to its nearer child
-            const uint32_t ha = leaf ? (0x8000u | (self >> 1)) : base + down * 32u;
+            const uint32_t ha = leaf ? (0x8000u | ((f_as_u(q0.w) >> 24) << 11) | (f_as_u(q0.w) & 0x7FFu)) : base + down * 32u;
             const uint32_t ma = miss[o] == PT_END ? 0xFFFFu : base + miss[o] * 32u;
             word[o] = ha | (ma << 16);
           }

@@ -138,6 +138,7 @@ float frame_nb_inverse(float c)
   return 1.0f / c;
 }
 constexpr uint32_t kCompactMaxNodes = 896;   // 896 * 32 B = 28 KB of boxes below 0x8000 with 4 KB to spare for static LDS
+constexpr uint32_t kCompactMaxTris = 2047;   // a leaf's link code holds count << 11 | first triangle record in 15 bits (stage_scene)
 constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit); a 128-byte stride (one line per record) measured -0.7 % on the atrium
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
 constexpr uint32_t kMaxLeaf = 3;   // 3 beats 4 by 1.2 % now that a box test costs a third of a triangle test (scripts/gpu_knobs.sh)
@@ -323,7 +324,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
   const int kind = which == PTAMD_KERNEL_BRUTE_FORCE ? 1 : 2;
   const size_t lds = kind == 1 ? s.info.lds_bytes_brute : s.info.lds_bytes_bvh;
   // the LDS copy of a BVH addresses its boxes with 15 bits (pt_kernels.hip: stage_scene): 32 bytes per node, nodes first
-  const bool resident = lds <= kLdsBudget && (kind == 1 || s.n_nodes <= kCompactMaxNodes);
+  const bool resident = lds <= kLdsBudget && (kind == 1 || (s.n_nodes <= kCompactMaxNodes && s.n_bvh_tris <= kCompactMaxTris));
   hipStream_t stream = static_cast<hipStream_t>(l->stream);
   // Per-stream state of the persistent kernels: sample slabs, events (found or made here, once per launch)
   ptamd_context::SampleScratch* sc = nullptr;
