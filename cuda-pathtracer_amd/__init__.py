@@ -10,7 +10,7 @@ from .native import (KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, KERNEL_BVH_PER
                      PtamdError)
 from .scene import (HostScene, cubemap_for_scene, cubemap_from_color, cubemap_from_cross,
                     FACE_DTYPE, MATERIAL_DTYPE, LIGHT_DTYPE, TEXTURE_DTYPE, CAMERA_DTYPE)
-from .render import (Context, FrameRenderer, host_bvh_trace, host_bvh4_trace, host_bvh8_trace, interleaved_rows, wang_hash, REFERENCE_BOUNCES,
+from .render import (Context, FrameRenderer, host_bvh_trace, host_bvh4_trace, host_bvh4q_trace, host_bvh8_trace, interleaved_rows, wang_hash, REFERENCE_BOUNCES,
                      POST_NONE, POST_GRAYSCALE, POST_SEPIA, POST_INVERT)
 from .tiles import row_bands, band_of_rank, BandGather, interleaved_bands, rank_times_ms, time_gather_ms
 from .synthetic import tessellate

@@ -320,7 +320,7 @@ struct KParams {
   uint32_t treelet_nodes;   // the first nodes of nodes4 (top of the tree) are staged in LDS in front of the stacks
   uint2* stack_spill;
   uint32_t walk_min4;
-  uint32_t wide8;                 // `nodes4` holds the eight-wide quantised form: selects the instantiation that walks it (PTAMD_WIDE8 knob)
+  uint32_t wide8;                 // which form `nodes4` holds: 0 four-wide float nodes, 1 the eight-wide quantised form (PTAMD_WIDE8 knob), 2 four-wide 64-byte quantised nodes
   uint32_t far_table[16];         // eight-wide walk: for ray octant o, byte c of the pair [2 o], [2 o + 1] = the slots visited after slot c
   uint32_t brute_walk;            // restart kernel: the launch wants the instantiation that tests every triangle record instead of walking the tree (far origin)
   unsigned long long* timeline;   // restart kernel: != nullptr selects the instantiation that records 4 time stamps per wave (ptamd_set_timeline)

@@ -1384,8 +1384,73 @@ PT_DEV uint32_t walk8_visit(const float4* nodes8, const Stack4& stk, const Walk&
   return next;
 }
 
+// ---------------------------------------------------------------- four-wide walk over 64-byte quantised nodes (late round 3)
+//
+// The same tree and numbering as the float form (Bvh::nodes4q): origin, per-axis power-of-two scale, 8-bit child planes rounded
+// outward, references, and the visiting order of octants 0..3 (an octant's opposite visits in the reverse order).  A visit is
+// FOUR 16-byte loads instead of eight: the CU's memory pipe is what binds this walk (doubling the loads of a visit, all of them L1
+// hits, cost 40-68 %: HISTORY.md).  The planes a ray enters / leaves through follow the SIGN BIT of its direction, as in the
+// eight-wide form.
+template <bool STATS>
+PT_DEV uint32_t walk4q_visit(const float4* nodesq, const Stack4& stk, const Walk& w, uint32_t soct, uint32_t cur, uint32_t& sp)
+{
+  uint4 hd, rf, pa, pb;
+  if (cur < stk.top_n) {
+    const uint4* q = reinterpret_cast<const uint4*>(stk.top) + cur * 4u;
+    hd = q[0]; rf = q[1]; pa = q[2]; pb = q[3];
+  } else {
+    const uint4* q = reinterpret_cast<const uint4*>(nodesq) + (size_t)cur * 4u;
+    hd = q[0]; rf = q[1]; pa = q[2]; pb = q[3];
+  }
+  // (references and order words are needed last, but fetched with the planes: one round trip per visit)
+  asm volatile("" : "+v"(rf.x), "+v"(rf.y), "+v"(rf.z), "+v"(rf.w), "+v"(pb.z), "+v"(pb.w));
+  // planes: pa = lo.x[4] lo.y[4] lo.z[4] hi.x[4], pb.xy = hi.y[4] hi.z[4]
+  const bool nx = (soct & 1u) != 0u, ny = (soct & 2u) != 0u, nz = (soct & 4u) != 0u;
+  const uint32_t enx = nx ? pa.w : pa.x, exx = nx ? pa.x : pa.w;
+  const uint32_t eny = ny ? pb.x : pa.y, exy = ny ? pa.y : pb.x;
+  const uint32_t enz = nz ? pb.y : pa.z, exz = nz ? pa.z : pb.y;
+  const float ax = u_as_f((hd.w & 0xFFu) << 23) * w.inv.x, ay = u_as_f(((hd.w >> 8) & 0xFFu) << 23) * w.inv.y,
+              az = u_as_f(((hd.w >> 16) & 0xFFu) << 23) * w.inv.z;
+  const float bx = __builtin_fmaf(u_as_f(hd.x), w.inv.x, w.noi.x), by = __builtin_fmaf(u_as_f(hd.y), w.inv.y, w.noi.y),
+              bz = __builtin_fmaf(u_as_f(hd.z), w.inv.z, w.noi.z);
+  float tn[4];
+  uint32_t hit = 0;
+#define PT_CHILDQ(c, SH)                                                                                                 \
+  {                                                                                                                      \
+    const float tnx = __builtin_fmaf((float)((enx >> SH) & 0xFFu), ax, bx), tfx = __builtin_fmaf((float)((exx >> SH) & 0xFFu), ax, bx); \
+    const float tny = __builtin_fmaf((float)((eny >> SH) & 0xFFu), ay, by), tfy = __builtin_fmaf((float)((exy >> SH) & 0xFFu), ay, by); \
+    const float tnz = __builtin_fmaf((float)((enz >> SH) & 0xFFu), az, bz), tfz = __builtin_fmaf((float)((exz >> SH) & 0xFFu), az, bz); \
+    tn[c] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz), 0.0f);                                      \
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fminf(tfx, tfy), tfz), w.best.t);                         \
+    if (tn[c] <= tf) hit |= 1u << c;                                                                                     \
+  }
+  PT_CHILDQ(0, 0) PT_CHILDQ(1, 8) PT_CHILDQ(2, 16) PT_CHILDQ(3, 24)
+#undef PT_CHILDQ
+  if (hit == 0u) return stack4_pop(stk, sp, w.best.t);
+  // halfword h of pb.zw: the order of octant h (0..3); octants 4..7 read the opposite octant's, inverted — every nibble then also
+  // names its own child, which the rank below takes off again
+  const uint32_t h = nz ? (~soct & 3u) : soct;
+  uint32_t order = ((h & 2u) ? pb.w : pb.z) >> ((h & 1u) << 4);
+  if (nz) order = ~order;
+  const uint32_t self_counted = nz ? 1u : 0u;
+  const uint32_t nhit = (uint32_t)__builtin_popcount(hit);
+  const uint32_t ref[4] = { rf.x, rf.y, rf.z, rf.w };
+  uint32_t next = PT_NONE;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if ((hit >> c) & 1u) {
+      const uint32_t rank = (uint32_t)__builtin_popcount(hit & (order >> (4 * c)) & 0xFu) - self_counted;
+      if (rank + 1u == nhit) next = ref[c];
+      else stack4_write(stk, sp + rank, ref[c], tn[c]);
+    }
+  }
+  sp += nhit - 1u;
+  return next;
+}
+
 // One round of the wide walk for the lanes that call it (see traverse_round): cur == PT_NONE on return: finished.
-template <bool STATS, bool WIDE8 = false>
+// MODE: 0 four-wide float nodes, 1 eight-wide quantised nodes, 2 four-wide quantised nodes
+template <bool STATS, int MODE = 0>
 PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4* tris, const Stack4& stk, f3 o, f3 d, Best& best, uint32_t& cur,
                             uint32_t& sp, uint32_t round_min, uint32_t round_div, uint32_t walk_min, bool small_det, Counters& cnt)
 {
@@ -1394,7 +1459,8 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
   w.best = best;
   Walk8 x8;
   x8.oct = 0u; x8.far = make_uint2(0u, 0u);
-  if (WIDE8) x8 = walk8_init(p, d);
+  if (MODE == 1) x8 = walk8_init(p, d);
+  if (MODE == 2) x8.oct = (f_as_u(d.x) >> 31) | ((f_as_u(d.y) >> 31) << 1) | ((f_as_u(d.z) >> 31) << 2);
   const uint32_t n_start = (uint32_t)__popcll(__ballot(cur != PT_NONE));
   uint32_t t_eff = (n_start + round_div - 1u) / round_div;
   if (t_eff > round_min) t_eff = round_min;
@@ -1410,7 +1476,8 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
           cnt.nodes++;
           if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) cnt.wave_node_iters++;
         }
-        if (WIDE8) cur = walk8_visit<STATS>(nodes4, stk, w, x8, cur, sp);
+        if (MODE == 1) cur = walk8_visit<STATS>(nodes4, stk, w, x8, cur, sp);
+        else if (MODE == 2) cur = walk4q_visit<STATS>(nodes4, stk, w, x8.oct, cur, sp);
         else cur = walk4_visit<STATS>(nodes4, stk, w, cur, sp);
       }
       if (walkers < walk_min) break;
@@ -1460,6 +1527,7 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
 #define PT_RS_STAMPS 2
 #define PT_RS_BRUTE 3
 #define PT_RS_WIDE8 4   /* scenes that do not fit in LDS walked in the eight-wide quantised form (Bvh::nodes8) instead of the four-wide one */
+#define PT_RS_WIDE4Q 5  /* ... in the four-wide form with 64-byte quantised nodes (Bvh::nodes4q) */
 
 template <bool LDS_RESIDENT, int VARIANT>
 __global__ void __launch_bounds__(LDS_RESIDENT ? PT_RS_THREADS : PT_RS4_THREADS, LDS_RESIDENT ? PT_RS_WAVES_PER_EU : PT_RS4_WAVES_PER_EU)
@@ -1483,12 +1551,13 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
   Stack4 stk;
   stk.top = s_mem;
   stk.top_n = WIDE ? p.treelet_nodes : 0u;
+  constexpr uint32_t NODE_F4 = VARIANT == PT_RS_WIDE4Q ? 4u : 8u;   // float4 per wide node
   if (WIDE) {
-    stage_to_lds(s_mem, p.nodes4, p.treelet_nodes * 8u);
+    stage_to_lds(s_mem, p.nodes4, p.treelet_nodes * NODE_F4);
     __syncthreads();
   }
   PT_STAMP(1);
-  stk.lds = reinterpret_cast<uint2*>(s_mem + (size_t)p.treelet_nodes * 8u) + (size_t)(threadIdx.x >> 6) * p.stack_lds_entries * 64u + lane;
+  stk.lds = reinterpret_cast<uint2*>(s_mem + (size_t)p.treelet_nodes * NODE_F4) + (size_t)(threadIdx.x >> 6) * p.stack_lds_entries * 64u + lane;
   stk.spill = p.stack_spill + (size_t)gwave * p.stack_spill_entries * 64u + lane;
   stk.lds_entries = p.stack_lds_entries;
   uint32_t cur = PT_NONE, sp = 0;   // wide walk: reference to process next, entries on the stack
@@ -1613,7 +1682,7 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
         if (STATS) cnt.tris += p.n_bvh_tris;
         node = PT_END;
       } else if (WIDE) {
-        traverse_round4<STATS, VARIANT == PT_RS_WIDE8>(p, p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, p.small_det != 0u, cnt);
+        traverse_round4<STATS, VARIANT == PT_RS_WIDE8 ? 1 : (VARIANT == PT_RS_WIDE4Q ? 2 : 0)>(p, p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, p.small_det != 0u, cnt);
         node = cur == PT_NONE ? PT_END : 0u;
       } else {
         traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.walk_min, p.small_det != 0u, cnt);
@@ -2094,7 +2163,7 @@ __global__ void __launch_bounds__(256) pt_resolve_kernel4(PT_KERNEL_PARAMS)
 }
 
 // The same query through the four-wide walk: one wave per block, the stack entirely in (dynamic) LDS.
-template <bool WIDE8>
+template <int MODE>
 __global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(PT_KERNEL_PARAMS, const float* rays, uint32_t n, int4* out)
 {
   extern __shared__ float4 s_mem[];
@@ -2112,7 +2181,7 @@ __global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(PT_KERNEL_PARAMS
   Best best;
   best.t = PT_MAX_DIST; best.u = best.v = 0.f; best.idx = PT_END;
   uint32_t cur = (live && p.n_nodes4) ? 0u : PT_NONE, sp = 0u;
-  if (live) traverse_round4<false, WIDE8>(p, p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, p.small_det != 0u, cnt);
+  if (live) traverse_round4<false, MODE>(p, p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, p.small_det != 0u, cnt);
   if (!live) return;
   Nearest nr;
   nr.t = best.t; nr.u = best.u; nr.v = best.v; nr.idx = best.idx;
@@ -2218,6 +2287,7 @@ static const void* restart_entry(int variant)
     case PT_RS_STAMPS: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_STAMPS>);
     case PT_RS_BRUTE: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_BRUTE>);
     case PT_RS_WIDE8: return reinterpret_cast<const void*>(pt_megakernel_restart<false, PT_RS_WIDE8>);   // (only ever a non-resident scene)
+    case PT_RS_WIDE4Q: return reinterpret_cast<const void*>(pt_megakernel_restart<false, PT_RS_WIDE4Q>);
     default: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_PLAIN>);
   }
 }
@@ -2225,7 +2295,7 @@ static const void* restart_entry(int variant)
 // variant: instrumented build when counters are wanted, else the far-origin form, else the time-stamp form, else the shipped kernel
 static const void* restart_select(bool lds_resident, bool stats, const KParams* p = nullptr)
 {
-  const int variant = stats ? PT_RS_STATS : (p && p->brute_walk ? PT_RS_BRUTE : (p && p->timeline ? PT_RS_STAMPS : (p && p->wide8 && !lds_resident ? PT_RS_WIDE8 : PT_RS_PLAIN)));
+  const int variant = stats ? PT_RS_STATS : (p && p->brute_walk ? PT_RS_BRUTE : (p && p->timeline ? PT_RS_STAMPS : (p && p->wide8 && !lds_resident ? (p->wide8 == 2u ? PT_RS_WIDE4Q : PT_RS_WIDE8) : PT_RS_PLAIN)));
   return lds_resident ? restart_entry<true>(variant) : restart_entry<false>(variant);
 }
 
@@ -2374,7 +2444,7 @@ hipError_t resolve_kernels()
     persistent_select(true, false), persistent_select(false, false), persistent_select(true, true), persistent_select(false, true),
     split_select(true, false), split_select(false, false), blockwise_select(true, false), blockwise_select(false, false),
     restart_entry<true>(PT_RS_PLAIN), restart_entry<false>(PT_RS_PLAIN), restart_entry<true>(PT_RS_STATS), restart_entry<false>(PT_RS_STATS),
-    restart_entry<true>(PT_RS_STAMPS), restart_entry<false>(PT_RS_STAMPS), restart_entry<true>(PT_RS_BRUTE), restart_entry<false>(PT_RS_BRUTE), restart_entry<false>(PT_RS_WIDE8),
+    restart_entry<true>(PT_RS_STAMPS), restart_entry<false>(PT_RS_STAMPS), restart_entry<true>(PT_RS_BRUTE), restart_entry<false>(PT_RS_BRUTE), restart_entry<false>(PT_RS_WIDE8), restart_entry<false>(PT_RS_WIDE4Q),
     reinterpret_cast<const void*>(pt_megakernel<1, true, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_megakernel<1, false, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_megakernel<2, true, false, PT_TILE_THREADS>),
@@ -2398,12 +2468,14 @@ hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, 
   if (kind == 3) {   // four-wide walk; p.stack_lds_entries covers the whole stack (3 x depth of the wide tree)
     const size_t lds = (size_t)p.stack_lds_entries * 64u * sizeof(uint2);
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(p.wide8 ? reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<true>) : reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const void* fn = p.wide8 == 1u ? reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<1>)
+                     : (p.wide8 == 2u ? reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<2>) : reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<0>));
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    if (p.wide8) hipLaunchKernelGGL(pt_trace_rays_wide_kernel<true>, dim3((n + 63u) / 64u), dim3(64), lds, stream, p, rays_dev, n, out_dev);
-    else hipLaunchKernelGGL(pt_trace_rays_wide_kernel<false>, dim3((n + 63u) / 64u), dim3(64), lds, stream, p, rays_dev, n, out_dev);
+    if (p.wide8 == 1u) hipLaunchKernelGGL(pt_trace_rays_wide_kernel<1>, dim3((n + 63u) / 64u), dim3(64), lds, stream, p, rays_dev, n, out_dev);
+    else if (p.wide8 == 2u) hipLaunchKernelGGL(pt_trace_rays_wide_kernel<2>, dim3((n + 63u) / 64u), dim3(64), lds, stream, p, rays_dev, n, out_dev);
+    else hipLaunchKernelGGL(pt_trace_rays_wide_kernel<0>, dim3((n + 63u) / 64u), dim3(64), lds, stream, p, rays_dev, n, out_dev);
     return hipGetLastError();
   }
   dim3 grid((n + 255u) / 256u);

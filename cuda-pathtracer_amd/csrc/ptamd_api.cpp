@@ -36,6 +36,7 @@ struct DeviceScene {
   float4* nodes = nullptr;
   float4* nodes4 = nullptr;   // the four-wide form of the same tree (8 float4 per node)
   float4* nodes8 = nullptr;   // ... and the eight-wide quantised form (8 float4 per node): walked instead when PTAMD_WIDE8=1 (tuning)
+  float4* nodes4q = nullptr;  // ... and the four-wide form in 64-byte quantised nodes (4 float4 per node, numbered as nodes4)
   uint32_t n_nodes8 = 0, depth8 = 0;
   float4* tris_bvh = nullptr;
   float4* tris_brute = nullptr;
@@ -106,6 +107,7 @@ struct ptamd_context {
   // a host that simply calls raytrace() again without synchronising (gpu_processor.cpp:365-386 does not).
   hipStream_t internal[2] = { nullptr, nullptr };
   bool overlap = true;                    // PTAMD_OVERLAP=0 (tuning): everything on the caller's stream
+  bool wide4q = false;                    // PTAMD_WIDE4Q=1 (tuning): big scenes walk the 64-byte quantised four-wide nodes
   bool wide8 = false;                     // PTAMD_WIDE8=1 (tuning): big scenes walk the eight-wide quantised nodes (measured 8 % slower: DESIGN.md §4)
   unsigned long long* d_timeline = nullptr;   // ptamd_set_timeline: 4 time stamps per wave of the restart kernel
   uint32_t timeline_waves = 0;
@@ -177,7 +179,7 @@ int upload(T*& dst, const void* src, size_t bytes)
 
 void free_scene(DeviceScene& s)
 {
-  void* ptrs[] = { s.nodes, s.nodes4, s.nodes8, s.tris_bvh, s.tris_brute, s.shade, s.materials, s.lights, s.textures, s.texels };
+  void* ptrs[] = { s.nodes, s.nodes4, s.nodes8, s.nodes4q, s.tris_bvh, s.tris_brute, s.shade, s.materials, s.lights, s.textures, s.texels };
   for (void* q : ptrs) (void)hipFree(q);
   s = DeviceScene();
 }
@@ -432,6 +434,9 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       // the eight-wide quantised form instead of the four-wide one (knob; not for the instrumented / time-stamp / far-origin instantiations)
       const bool wide8 = ctx->wide8 && !stats && !p.brute_walk && !ctx->d_timeline && s.n_nodes8 != 0;
       if (wide8) { p.nodes4 = s.nodes8; p.n_nodes4 = s.n_nodes8; p.wide8 = 1u; }
+      const bool wide4q = !wide8 && ctx->wide4q && !stats && !p.brute_walk && !ctx->d_timeline && s.nodes4q != nullptr;
+      if (wide4q) { p.nodes4 = s.nodes4q; p.wide8 = 2u; }
+      const uint32_t node_bytes = wide4q ? 64u : 128u;
       const uint32_t need = (wide8 ? 7u * s.depth8 : 3u * s.depth4) + 1u;   // a visit stacks all hit children but the nearest
       const uint32_t waves = restart_threads(false) / 64u;
       const uint32_t share = 160u * 1024u / restart_wide_blocks_per_cu() - 256u;   // LDS bytes of one resident workgroup
@@ -439,14 +444,16 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       // 512 nodes = 64 KB of the one workgroup's 160 KB, then 7 stack entries per lane
       // ... and the waves' pools of fresh paths (PT_POOL_LDS_BYTES each), behind the stacks
       const uint32_t pools = ctx->pool_in_lds ? waves * PT_POOL_LDS_BYTES : 0u;
-      uint32_t treelet = ctx->treelet_nodes < p.n_nodes4 ? ctx->treelet_nodes : p.n_nodes4;
-      if (treelet * 128u + waves * 512u * 4u + pools > share) treelet = (share - pools - waves * 512u * 4u) / 128u;   // keep >= 4 stack entries
-      uint32_t fit = (share - pools - treelet * 128u) / (waves * 512u);
+      // (the same LDS bytes hold twice as many 64-byte nodes)
+      const uint32_t treelet_want = ctx->treelet_nodes * (128u / node_bytes);
+      uint32_t treelet = treelet_want < p.n_nodes4 ? treelet_want : p.n_nodes4;
+      if (treelet * node_bytes + waves * 512u * 4u + pools > share) treelet = (share - pools - waves * 512u * 4u) / node_bytes;   // keep >= 4 stack entries
+      uint32_t fit = (share - pools - treelet * node_bytes) / (waves * 512u);
       if (const char* ev = tuning_env("PTAMD_STACK_LDS")) { int v = std::atoi(ev); if (v >= 1 && (uint32_t)v <= fit) fit = (uint32_t)v; }   // tuning knob
       p.treelet_nodes = treelet;
       p.stack_lds_entries = need < fit ? need : fit;
       p.stack_spill_entries = need - p.stack_lds_entries;
-      launch_lds = (size_t)treelet * 128u + (size_t)p.stack_lds_entries * waves * 512u;
+      launch_lds = (size_t)treelet * node_bytes + (size_t)p.stack_lds_entries * waves * 512u;
       if (pools) {
         p.pool_lds_offset = (uint32_t)launch_lds;
         if (!p.pool_lds_offset) p.pool_lds_offset = 16u;
@@ -678,6 +685,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   }
   if (const char* e = tuning_env("PTAMD_SHORT_RCP")) ctx->short_rcp = std::atoi(e) != 0; // tuning knob
   if (const char* e = tuning_env("PTAMD_WIDE8")) ctx->wide8 = std::atoi(e) != 0; // tuning knob
+  if (const char* e = tuning_env("PTAMD_WIDE4Q")) ctx->wide4q = std::atoi(e) != 0; // tuning knob
   if (const char* e = tuning_env("PTAMD_POOL_LDS")) ctx->pool_in_lds = std::atoi(e) != 0; // tuning knob
   if (const char* e = tuning_env("PTAMD_TREELET")) { // tuning knob
     int v = std::atoi(e);
@@ -814,6 +822,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
       (rc = upload(d.nodes4, bvh.nodes4.data(), bvh.nodes4.size() * 4)) ||
       (rc = upload(d.nodes8, bvh.nodes8.data(), bvh.nodes8.size() * 4)) ||
+      (rc = upload(d.nodes4q, bvh.nodes4q.data(), bvh.nodes4q.size() * 4)) ||
       (rc = upload(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4)) ||
       (rc = upload(d.tris_brute, brute.data(), brute.size() * 4)) ||
       (rc = upload(d.shade, shade.data(), shade.size() * 4)) ||
@@ -1006,6 +1015,7 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   p.small_det = 0u;                           // caller-supplied directions need not be unit vectors
   p.stack_lds_entries = 3u * s.depth4 + 1u;   // PTAMD_KERNEL_BVH_RESTART: the wide walk, whole stack in LDS
   if (ctx->wide8 && s.n_nodes8 != 0) { p.nodes4 = s.nodes8; p.n_nodes4 = s.n_nodes8; p.wide8 = 1u; p.stack_lds_entries = 7u * s.depth8 + 1u; }
+  else if (ctx->wide4q && s.nodes4q != nullptr) { p.nodes4 = s.nodes4q; p.wide8 = 2u; }
   float* d_rays = nullptr;
   int4* d_out = nullptr;
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));

@@ -508,6 +508,98 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
       }
       for (int i = 0; i < 4; ++i) q[28 + i] = u2f(words[i]);
     }
+
+    // ---- ... and the same four-wide nodes in 64 bytes (Bvh::nodes4q): child boxes as 8-bit planes on a per-node grid (float
+    // origin, one power-of-two scale per axis), rounded outward.  Half the bytes and half the load instructions per visit.
+    // The visiting order of an octant and of its opposite are each other's reverse: only octants 0..3 are stored.
+    out.nodes4q.assign((size_t)out.n_nodes4 * 16, 0u);
+    const float mq = margin + 2.0f * origin_margin;   // (two more roundings in the slab arithmetic than the float form: as for nodes8)
+    for (size_t w = 0; w < wide.size(); ++w) {
+      uint32_t* q = &out.nodes4q[w * 16];
+      float lo_c[4][3], hi_c[4][3];
+      float nlo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, nhi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+      for (int c = 0; c < 4; ++c) {
+        if (wide[w].child[c] < 0) continue;
+        const BuildNode& cn = b.nodes[(size_t)wide[w].child[c]];
+        for (int a = 0; a < 3; ++a) {
+          lo_c[c][a] = cn.box.lo[a] - (mq + std::fabs(cn.box.lo[a]) * 1e-6f);
+          hi_c[c][a] = cn.box.hi[a] + (mq + std::fabs(cn.box.hi[a]) * 1e-6f);
+          nlo[a] = std::min(nlo[a], lo_c[c][a]);
+          nhi[a] = std::max(nhi[a], hi_c[c][a]);
+        }
+      }
+      uint32_t expo[3];
+      float scale[3];
+      for (int a = 0; a < 3; ++a) {
+        int e = 0;
+        const float ext = nhi[a] - nlo[a];
+        if (ext > 0.0f && ext <= std::numeric_limits<float>::max()) { (void)std::frexp(ext / 255.0f, &e); }   // 2^e >= ext / 255
+        else if (!(ext <= std::numeric_limits<float>::max())) e = 120;
+        else e = -120;
+        e = std::max(-120, std::min(120, e));
+        expo[a] = (uint32_t)(e + 127);
+        scale[a] = std::ldexp(1.0f, e);
+        q[a] = f2u(nlo[a]);
+      }
+      q[3] = expo[0] | (expo[1] << 8) | (expo[2] << 16) | ((uint32_t)wide[w].n << 24);
+      uint8_t qlo[3][4], qhi[3][4];
+      float key[4][4];
+      for (int c = 0; c < 4; ++c) {
+        uint32_t ref = 0xFFFFFFFFu;
+        if (wide[w].child[c] < 0) {
+          for (int a = 0; a < 3; ++a) { qlo[a][c] = 255; qhi[a][c] = 0; }   // inverted: no ray enters before it leaves
+        } else {
+          const BuildNode& cn = b.nodes[(size_t)wide[w].child[c]];
+          for (int a = 0; a < 3; ++a) {
+            // rounded outward, then checked with the device's own decode: fma(q, scale, origin) must enclose the child
+            int l = (int)std::floor((lo_c[c][a] - nlo[a]) / scale[a]);
+            int h = (int)std::ceil((hi_c[c][a] - nlo[a]) / scale[a]);
+            if (!(lo_c[c][a] == lo_c[c][a]) || !(hi_c[c][a] == hi_c[c][a])) { l = 0; h = 255; }
+            l = std::max(0, std::min(255, l));
+            h = std::max(0, std::min(255, h));
+            while (l > 0 && !(std::fma((float)l, scale[a], nlo[a]) <= lo_c[c][a])) --l;
+            while (h < 255 && !(std::fma((float)h, scale[a], nlo[a]) >= hi_c[c][a])) ++h;
+            qlo[a][c] = (uint8_t)l;
+            qhi[a][c] = (uint8_t)h;
+          }
+          if (cn.left < 0) {
+            const uint32_t info = leaf_info[(size_t)wide[w].child[c]];
+            ref = 0x80000000u | ((info >> 24) << 24) | (info & 0xFFFFFFu);
+          } else {
+            ref = (uint32_t)wide_of[(size_t)wide[w].child[c]];
+          }
+          for (int o = 0; o < 4; ++o) {
+            float k = 0.0f;
+            for (int a = 0; a < 3; ++a) {
+              const float ctr = 0.5f * cn.box.lo[a] + 0.5f * cn.box.hi[a];
+              k += ((o >> a) & 1) ? -ctr : ctr;
+            }
+            key[c][o] = k;
+          }
+        }
+        q[4 + c] = ref;
+      }
+      for (int a = 0; a < 3; ++a) {
+        std::memcpy(&q[8 + a], qlo[a], 4);
+        std::memcpy(&q[11 + a], qhi[a], 4);
+      }
+      uint32_t words[2] = { 0, 0 };
+      for (int o = 0; o < 4; ++o) {
+        uint32_t half = 0;
+        for (int c = 0; c < 4; ++c) {
+          if (wide[w].child[c] < 0) continue;
+          uint32_t farther = 0;
+          for (int d = 0; d < 4; ++d) {
+            if (d == c || wide[w].child[d] < 0) continue;
+            if (key[d][o] > key[c][o] || (key[d][o] == key[c][o] && d > c)) farther |= 1u << d;
+          }
+          half |= farther << (4 * c);
+        }
+        words[o >> 1] |= half << (16 * (o & 1));
+      }
+      q[14] = words[0];
+      q[15] = words[1];
+    }
   }
 
   // ---- the same tree once more, collapsed to EIGHT children per node with quantised child boxes (layout: ptamd_internal.h,
@@ -732,13 +824,16 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
 // Mirror of the device's four-wide walk (csrc/pt_kernels.hip: walk4_*): a stack of (reference, entry distance); a node's
 // hit children are pushed farthest first in the node's order for the ray's octant; entries whose entry distance lies
 // beyond the best hit are dropped when popped.  Result contract as for the binary walk.
-void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
-                     uint64_t* tris_tested)
+static void bvh4_trace_impl(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
+                            uint64_t* tris_tested, bool quantised)
 {
   const float MAX_DIST = 100000.0f;
   float best_t = MAX_DIST, best_u = 0.f, best_v = 0.f;
   uint32_t best_idx = 0xFFFFFFFFu;
   const int oct = (dir[0] < 0.f ? 1 : 0) | (dir[1] < 0.f ? 2 : 0) | (dir[2] < 0.f ? 4 : 0);
+  // the quantised form takes the octant from the SIGN BITS (-0.0 counts as negative: its stand-in below is -1e-30, so the ray
+  // enters through the high plane)
+  const uint32_t soct = (std::signbit(dir[0]) ? 1u : 0u) | (std::signbit(dir[1]) ? 2u : 0u) | (std::signbit(dir[2]) ? 4u : 0u);
   float inv[3], noi[3];
   for (int a = 0; a < 3; ++a) {
     const float da = std::fabs(dir[a]) < 1e-30f ? std::copysign(1e-30f, dir[a]) : dir[a];
@@ -777,7 +872,6 @@ void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], 
       }
       continue;
     }
-    const float* q = &bvh.nodes4[(size_t)e.ref * 32];
     if (nodes_visited) {
       ++*nodes_visited;
       if (e.ref < 85u) ++nodes_visited[3];    // counters[3], [4] of ptamd_host_bvh4_trace: visits to the first 85 / 341 nodes
@@ -785,28 +879,59 @@ void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], 
     }
     uint32_t hit = 0;
     float tn[4];
-    for (int c = 0; c < 4; ++c) {
-      float tnear = -std::numeric_limits<float>::infinity(), tfar = std::numeric_limits<float>::infinity();
-      for (int a = 0; a < 3; ++a) {
-        const float tc = std::fma(q[a * 4 + c], inv[a], noi[a]), ai = std::fabs(inv[a]);
-        tnear = std::max(tnear, std::fma(-q[12 + a * 4 + c], ai, tc));
-        tfar = std::min(tfar, std::fma(q[12 + a * 4 + c], ai, tc));
+    uint32_t order, refs[4];
+    int self_counted = 0;   // quantised form, octants 4..7: the stored order is the opposite octant's, read inverted
+    if (!quantised) {
+      const float* q = &bvh.nodes4[(size_t)e.ref * 32];
+      for (int c = 0; c < 4; ++c) {
+        float tnear = -std::numeric_limits<float>::infinity(), tfar = std::numeric_limits<float>::infinity();
+        for (int a = 0; a < 3; ++a) {
+          const float tc = std::fma(q[a * 4 + c], inv[a], noi[a]), ai = std::fabs(inv[a]);
+          tnear = std::max(tnear, std::fma(-q[12 + a * 4 + c], ai, tc));
+          tfar = std::min(tfar, std::fma(q[12 + a * 4 + c], ai, tc));
+        }
+        tn[c] = std::max(tnear, 0.0f);
+        if (tn[c] <= std::min(tfar, best_t)) hit |= 1u << c;
+        std::memcpy(&refs[c], &q[24 + c], 4);
       }
-      tn[c] = std::max(tnear, 0.0f);
-      if (tn[c] <= std::min(tfar, best_t)) hit |= 1u << c;
+      uint32_t w;
+      std::memcpy(&w, &q[28 + (oct >> 1)], 4);
+      order = (w >> (16 * (oct & 1))) & 0xFFFFu;
+    } else {
+      // the device's operations (pt_kernels.hip: walk4q_visit): A = scale / d, B = fma(origin, 1/d, -o/d), t = fma(plane, A, B)
+      const uint32_t* q = &bvh.nodes4q[(size_t)e.ref * 16];
+      float A[3], B[3];
+      for (int a = 0; a < 3; ++a) {
+        float sc, org;
+        const uint32_t sb = ((q[3] >> (8 * a)) & 0xFFu) << 23;
+        std::memcpy(&sc, &sb, 4);
+        std::memcpy(&org, &q[a], 4);
+        A[a] = sc * inv[a];
+        B[a] = std::fma(org, inv[a], noi[a]);
+      }
+      for (int c = 0; c < 4; ++c) {
+        float tnear = -std::numeric_limits<float>::infinity(), tfar = std::numeric_limits<float>::infinity();
+        for (int a = 0; a < 3; ++a) {
+          const uint32_t lo = (q[8 + a] >> (8 * c)) & 0xFFu, hi = (q[11 + a] >> (8 * c)) & 0xFFu;
+          const bool neg = ((soct >> a) & 1u) != 0u;
+          tnear = std::max(tnear, std::fma((float)(neg ? hi : lo), A[a], B[a]));
+          tfar = std::min(tfar, std::fma((float)(neg ? lo : hi), A[a], B[a]));
+        }
+        tn[c] = std::max(tnear, 0.0f);
+        if (tn[c] <= std::min(tfar, best_t)) hit |= 1u << c;
+        refs[c] = q[4 + c];
+      }
+      const uint32_t h = (soct & 4u) ? (~soct & 3u) : (soct & 3u);
+      order = (q[14 + (h >> 1)] >> (16 * (h & 1u))) & 0xFFFFu;
+      if (soct & 4u) { order = ~order & 0xFFFFu; self_counted = 1; }
     }
-    uint32_t w;
-    std::memcpy(&w, &q[28 + (oct >> 1)], 4);
-    const uint32_t order = (w >> (16 * (oct & 1))) & 0xFFFFu;
     // farthest first: a child goes below every child that is nearer than it
     Entry pushed[4];
     const int nhit = __builtin_popcount(hit);
     for (int c = 0; c < 4; ++c) {
       if (!((hit >> c) & 1u)) continue;
-      const int rank = __builtin_popcount(hit & ((order >> (4 * c)) & 0xFu));   // hit children farther than c
-      uint32_t ref;
-      std::memcpy(&ref, &q[24 + c], 4);
-      pushed[nhit - 1 - rank] = { ref, tn[c] };     // nearest last = on top
+      const int rank = __builtin_popcount(hit & ((order >> (4 * c)) & 0xFu)) - self_counted;   // hit children farther than c
+      pushed[nhit - 1 - rank] = { refs[c], tn[c] };     // nearest last = on top
     }
     // pushed[] is in stack order: index 0 deepest (farthest)
     for (int i = 0; i < nhit; ++i) stack.push_back(pushed[i]);
@@ -814,6 +939,18 @@ void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], 
   out.kind = best_idx == 0xFFFFFFFFu ? 0 : 1;
   out.index = best_idx == 0xFFFFFFFFu ? -1 : (int32_t)best_idx;
   out.t = best_t; out.u = best_u; out.v = best_v;
+}
+
+void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
+                     uint64_t* tris_tested)
+{
+  bvh4_trace_impl(bvh, dir, origin, out, nodes_visited, tris_tested, false);
+}
+// ... over the 64-byte quantised nodes (Bvh::nodes4q)
+void bvh4q_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
+                      uint64_t* tris_tested)
+{
+  bvh4_trace_impl(bvh, dir, origin, out, nodes_visited, tris_tested, true);
 }
 
 // Mirror of the device's eight-wide walk (csrc/pt_kernels.hip: walk8_*): child boxes decoded from the node's origin, per-axis
@@ -1013,6 +1150,26 @@ extern "C" int ptamd_host_bvh4_trace(const ptamd_face* faces, uint32_t n_faces, 
     ptamd::HostHit h;
     ptamd::bvh4_trace_host(bvh, rays + (size_t)i * 6, rays + (size_t)i * 6 + 3, h,
                            counters ? &counters[0] : nullptr, counters ? &counters[1] : nullptr);
+    out[i * 4 + 0] = h.kind;
+    out[i * 4 + 1] = h.index;
+    std::memcpy(&out[i * 4 + 2], &h.t, 4);
+    out[i * 4 + 3] = 0;
+  }
+  if (counters) counters[2] = bvh.depth4;
+  return PTAMD_OK;
+}
+
+extern "C" int ptamd_host_bvh4q_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
+                                      int32_t* out, uint64_t* counters)
+{
+  if ((n_faces && !faces) || (n && (!rays || !out))) { ptamd::set_error("ptamd_host_bvh4q_trace: null argument"); return PTAMD_ERR_ARG; }
+  ptamd::Bvh bvh;
+  int rc = ptamd::build_bvh(faces, n_faces, 1e-3f, 3, bvh);
+  if (rc != PTAMD_OK) return rc;
+  for (uint32_t i = 0; i < n; ++i) {
+    ptamd::HostHit h;
+    ptamd::bvh4q_trace_host(bvh, rays + (size_t)i * 6, rays + (size_t)i * 6 + 3, h,
+                            counters ? &counters[0] : nullptr, counters ? &counters[1] : nullptr);
     out[i * 4 + 0] = h.kind;
     out[i * 4 + 1] = h.index;
     std::memcpy(&out[i * 4 + 2], &h.t, 4);

@@ -79,6 +79,13 @@ struct Bvh {
   // Nodes are numbered breadth-first (node 0 = root).  Leaves point into `tris`.
   std::vector<float> nodes4;
   uint32_t n_nodes4 = 0, depth4 = 0;
+  // The same four-wide nodes (same numbering, same references) in 64 bytes: 16 dwords
+  //   [0..2] origin (float)   [3] exponent bytes ex | ey << 8 | ez << 16 (scale[a] = 2^(e[a] - 127)), child count << 24
+  //   [4..7] reference[4]     [8..10] low planes x[4] y[4] z[4], one byte per child   [11..13] high planes x[4] y[4] z[4]
+  //          child box = origin + plane * scale, low planes rounded down, high planes up; an empty slot has low 255, high 0
+  //   [14..15] halfword o (octants 0..3): nibble c = the children octant o visits AFTER child c; octant 7 - o visits them in
+  //          the reverse order
+  std::vector<uint32_t> nodes4q;
   // ... and with EIGHT children per node and quantised child boxes: the walk of scenes that do not fit in LDS.  node record =
   // 32 dwords = ONE 128-byte line:
   //   [0..2]   origin (float): the low corner of the node's (inflated) box      [3] exponent bytes ex | ey << 8 | ez << 16
@@ -108,5 +115,7 @@ void bvh4_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], 
                      uint64_t* tris_tested);
 void bvh8_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
                      uint64_t* tris_tested);
+void bvh4q_trace_host(const Bvh& bvh, const float dir[3], const float origin[3], HostHit& out, uint64_t* nodes_visited,
+                      uint64_t* tris_tested);
 
 } // namespace ptamd

@@ -145,6 +145,8 @@ SIGNATURES = {
                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "ptamd_host_bvh4_trace": (C.c_int, [C.POINTER(Face), C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "ptamd_host_bvh4q_trace": (C.c_int, [C.POINTER(Face), C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "ptamd_host_bvh8_trace": (C.c_int, [C.POINTER(Face), C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "ptamd_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

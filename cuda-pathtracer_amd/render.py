@@ -205,6 +205,18 @@ def host_bvh4_trace(scene: HostScene, rays: np.ndarray):
     return out, counters[0], counters[1], counters[2]
 
 
+def host_bvh4q_trace(scene: HostScene, rays: np.ndarray):
+    """Host mirror of the four-wide walk over the 64-byte quantised nodes (test hook, no GPU): as host_bvh4_trace."""
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    out = np.zeros((len(rays), 4), dtype=np.int32)
+    counters = (C.c_uint64 * 5)(0, 0, 0, 0, 0)
+    N.check(N.load().ptamd_host_bvh4q_trace(scene.faces.ctypes.data_as(C.POINTER(N.Face)), len(scene.faces),
+                                            rays.ctypes.data_as(C.POINTER(C.c_float)), len(rays),
+                                            out.ctypes.data_as(C.POINTER(C.c_int32)), counters))
+    host_bvh4q_trace.top_visits = (counters[3], counters[4])
+    return out, counters[0], counters[1], counters[2]
+
+
 def host_bvh8_trace(scene: HostScene, rays: np.ndarray):
     """Host mirror of the device's eight-wide walk over quantised nodes (test hook, no GPU): (int32[n,4], nodes visited,
     triangles tested, depth, node count); .top_visits = visits to the first 73 / 585 nodes."""

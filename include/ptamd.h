@@ -354,6 +354,10 @@ int ptamd_host_bvh_trace(const ptamd_face* faces, uint32_t n_faces, const float*
  * in LDS is numbered first). */
 int ptamd_host_bvh4_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                           int32_t* out, uint64_t* counters);
+/* ... over the same four-wide nodes in their 64-byte form (8-bit child planes on a per-node grid), built with leaves of at most
+ * three triangles as the device uses them.  counters as above. */
+int ptamd_host_bvh4q_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
+                           int32_t* out, uint64_t* counters);
 
 /* ... and for the eight-wide form with quantised child boxes (one 128-byte line per node: origin, per-axis power-of-two
  * scale, 8-bit planes), built with leaves of at most three triangles as the device uses it.  counters (optional, 6 words):

@@ -239,3 +239,73 @@ def test_eight_wide_bvh_on_the_atrium(P, O, tmp_path):
     assert nodes8 / len(rays) <= 10.0 and depth <= 12 and top585 >= 0.6 * nodes8
     print("atrium: eight-wide nodes/ray %.2f (%.2f in the first 585 nodes), triangles/ray %.2f, depth %d, %d nodes; binary nodes/ray %.1f"
           % (nodes8 / len(rays), top585 / len(rays), tris8 / len(rays), depth, n_nodes, nodes2 / len(rays)))
+
+
+# ------------------------------------------------------------------ the four-wide form in 64-byte quantised nodes (round 3)
+
+@pytest.mark.parametrize("name", ["indoor", "crate_land", "color_sample", "island", "sss_crate"])
+def test_quantised_four_wide_bvh_equals_brute_force_on_assets(P, O, name):
+    """Bvh::nodes4q (origin + per-axis power-of-two scale + 8-bit planes rounded outward, order stored for four octants and
+    read inverted for the opposite four): the host mirror of the device walk returns the brute-force record for random rays
+    and for rays launched off the surfaces, and visits only slightly more nodes than the float form (looser boxes)."""
+    hs = P.HostScene.load(os.path.join(ASSETS, name + ".scene"))
+    rng = np.random.default_rng(23)
+    rays = random_rays(rng, 30000, extent=4.0)
+    f = hs.faces["vertices"][rng.integers(0, len(hs.faces), 15000)]
+    a, b = rng.uniform(size=(2, 15000, 1)).astype(np.float32)
+    flip = (a + b) > 1
+    a, b = np.where(flip, 1 - a, a), np.where(flip, 1 - b, b)
+    rays[:15000, 3:] = f[:, 0] + a * (f[:, 1] - f[:, 0]) + b * (f[:, 2] - f[:, 0]) + rays[:15000, :3] * np.float32(0.03)
+    want = O.intersect(lightless(O, P, hs), rays)
+    got, nodes, tris, depth = P.host_bvh4q_trace(hs, rays)
+    np.testing.assert_array_equal(got, want)
+    assert 1 <= depth <= 24 and nodes > 0
+
+
+def test_quantised_four_wide_bvh_ties_degenerates_signed_zeros_and_soup(P, O):
+    rng = np.random.default_rng(37)
+    base = random_soup(rng, 40)
+    hs = make_scene(P, np.concatenate([base, base[::-1], base]))          # coincident duplicates: lowest index wins
+    rays = random_rays(rng, 20000)
+    np.testing.assert_array_equal(P.host_bvh4q_trace(hs, rays)[0], O.intersect(lightless(O, P, hs), rays))
+    soup = make_scene(P, random_soup(rng, 3000, extent=3.0, size=0.25))
+    rays = random_rays(rng, 20000)
+    np.testing.assert_array_equal(P.host_bvh4q_trace(soup, rays)[0], O.intersect(lightless(O, P, soup), rays))
+    # axis-parallel rays with zeros of either sign (the planes a ray enters through follow the SIGN BIT of its direction)
+    rays[:50, 0] = 0.0
+    rays[50:100, 1:3] = 0.0
+    rays[100:150, 0] = -0.0
+    rays[150:200, 1:3] = -0.0
+    np.testing.assert_array_equal(P.host_bvh4q_trace(soup, rays)[0], O.intersect(lightless(O, P, soup), rays))
+    empty = make_scene(P, np.zeros((0, 3, 3), np.float32))
+    got = P.host_bvh4q_trace(empty, rays)[0]
+    assert (got[:, 0] == 0).all() and (got[:, 2].view(np.float32) == np.float32(100000.0)).all()
+    one = make_scene(P, np.float32([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]]))
+    np.testing.assert_array_equal(P.host_bvh4q_trace(one, rays)[0], O.intersect(lightless(O, P, one), rays))
+    tris = random_soup(rng, 64)
+    tris[3] = tris[3][0]
+    tris[10, 1, 2] = np.nan
+    weird = make_scene(P, tris)
+    np.testing.assert_array_equal(P.host_bvh4q_trace(weird, rays)[0], O.intersect(lightless(O, P, weird), rays))
+    for scale in (1.0e-4, 3.0e5):
+        big = make_scene(P, random_soup(rng, 500, extent=3.0, size=0.4) * np.float32(scale))
+        r = random_rays(rng, 4000, extent=3.0)
+        r[:, 3:] *= np.float32(scale)
+        np.testing.assert_array_equal(P.host_bvh4q_trace(big, r)[0], O.intersect(lightless(O, P, big), r))
+
+
+def test_quantised_four_wide_bvh_on_the_atrium(P, O, tmp_path):
+    """configs[3] asset: the quantised walk == the binary walk on 20 000 rays; node visits within 15 % of the float form."""
+    from cuda_pathtracer_amd.synthetic import write_atrium
+    hs = P.HostScene.load(write_atrium(str(tmp_path)))
+    rng = np.random.default_rng(31)
+    rays = random_rays(rng, 20000, extent=5.0)
+    rays[:, 3] *= 2.0
+    rays[:, 4] = np.abs(rays[:, 4]) + 0.2
+    gotq, nodesq, trisq, depth = P.host_bvh4q_trace(hs, rays)
+    got2, nodes2, tris2 = P.host_bvh_trace(hs, rays)
+    np.testing.assert_array_equal(gotq, got2)
+    got4, nodes4, tris4, depth4 = P.host_bvh4_trace(hs, rays)
+    assert nodesq <= 1.15 * nodes4
+    print("atrium: quantised four-wide nodes/ray %.2f (float form %.2f), triangles/ray %.2f (%.2f)"
+          % (nodesq / len(rays), nodes4 / len(rays), trisq / len(rays), tris4 / len(rays)))

@@ -425,6 +425,43 @@ def test_eight_wide_quantised_walk_on_the_device(P, O, monkeypatch):
         assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref, "eight-wide walk, batched")
 
 
+def test_quantised_four_wide_walk_on_the_device(P, O, monkeypatch):
+    """The four-wide tree in 64-byte quantised nodes (Bvh::nodes4q: float origin, per-axis power-of-two scale, 8-bit planes, the
+    order of four octants stored and read inverted for the opposite four; PTAMD_WIDE4Q=1): nearest-hit records == brute-force
+    oracle (zeros of either sign in the directions), rendered frames == oracle with the stack in LDS and mostly in the global
+    slab and with / without the LDS treelet, a batched launch == consecutive launches."""
+    import torch
+    monkeypatch.setenv("PTAMD_TUNING", "1")
+    monkeypatch.setenv("PTAMD_WIDE4Q", "1")
+    rng = np.random.default_rng(47)
+    with P.Context(0) as ctx:                       # (knobs are read when a context is created)
+        soup = make_scene(P, random_soup(rng, 3000, extent=3.0, size=0.25))
+        sid = ctx.upload_scene(soup)
+        rays = random_rays(rng, 20000)
+        rays[:40, 0] = 0.0
+        rays[40:80, 1:3] = -0.0
+        rays[80:120, 2] = -0.0                      # (octants 4..7 read the stored order inverted)
+        want = O.intersect(O.OracleScene.from_host_scene(soup, P.cubemap_from_color()), rays)
+        np.testing.assert_array_equal(ctx.trace_rays(sid, rays, P.KERNEL_BVH_RESTART), want)
+        assert (want[:, 0] == 1).sum() > 2000
+        hs = make_scene(P, random_soup(rng, 2500, extent=2.5, size=0.3), lights=[((0.0, 3.0, 1.0), (1, 1, 1), 6.0, 0.7)])
+        cube = synthetic_cubemap(rng, 4)
+        ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 96, 64, spp=2, bounces=4)
+        for knobs in ({}, {"PTAMD_STACK_LDS": "2"}, {"PTAMD_TREELET": "0"}, {"PTAMD_TREELET": "37", "PTAMD_STACK_LDS": "3"}):
+            for k, v in knobs.items():
+                monkeypatch.setenv(k, v)
+            with P.Context(0) as c2:
+                acc, rgba = gpu_render(P, c2, hs, cube, 96, 64, 2, 4, P.KERNEL_BVH_RESTART)
+            assert_same(acc, rgba, *ref, f"quantised four-wide walk, {knobs}")
+            for k in knobs:
+                monkeypatch.delenv(k)
+        ids = (ctx.upload_scene(hs), ctx.upload_cubemap(cube))
+        fr = P.FrameRenderer(ctx, *ids, hs.camera_struct(), 96, 64)
+        fr.render(spp=2, bounces=4, kernel=P.KERNEL_BVH_RESTART, batched=True)
+        torch.cuda.synchronize()
+        assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref, "quantised four-wide walk, batched")
+
+
 def test_scene_that_fills_the_lds_share_keeps_its_pools_in_global_memory(P, O, gpu_ctx):
     """An LDS-resident scene of 53-64 KB leaves no room for the restart kernel's path pools next to two scene copies: they
     go to the global slab instead (ptamd_api.cpp); same pixels either way."""
