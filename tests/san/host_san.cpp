@@ -1,11 +1,11 @@
 // host_san.cpp — sanitizer harness of the library's HOST code (scene / OBJ / MTL parser, JPEG / PNG / HDR decoders, PNG writer,
-// resampler, BVH builder and its three host walks).  Test infrastructure: built by `make san` with g++ -fsanitize=address,undefined
+// resampler, BVH builder and its four host walks).  Test infrastructure: built by `make san` with g++ -fsanitize=address,undefined
 // from the same sources the product library is built from (the device half, csrc/, is not part of it: GPU sanitizers are not
 // available on the pool) and run by tests/test_sanitizers.py.
 //
 //   host_san <assets dir> <scratch dir> <iterations> <seed>
 //
-// 1. every shipped asset through every loader entry point, every scene's faces through the builder and the three walks;
+// 1. every shipped asset through every loader entry point, every scene's faces through the builder and the four walks;
 // 2. `iterations` damaged copies of every input file class (bit flips, truncation, doubled chunks, hostile numbers in the text
 //    formats): the loaders may refuse a file, they may not read or write out of bounds, leak, or overflow.
 // Exit code 0: no finding (ASan / UBSan abort the process otherwise).
@@ -104,16 +104,18 @@ static void exercise_scene(const std::string& path, uint32_t flags, bool walk, s
       if (i % 193 == 0) r[(i + 1) % 3] = -0.0f;
       r[3] = cam.position.x + 3.0f * u(rng); r[4] = cam.position.y + 3.0f * u(rng); r[5] = cam.position.z + 3.0f * u(rng);
     }
-    std::vector<int32_t> a((size_t)n * 4), b((size_t)n * 4), c((size_t)n * 4);
-    uint64_t ca[2] = {0, 0}, cb[5] = {0, 0, 0, 0, 0}, cc[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<int32_t> a((size_t)n * 4), b((size_t)n * 4), c((size_t)n * 4), e((size_t)n * 4);
+    uint64_t ca[2] = {0, 0}, cb[5] = {0, 0, 0, 0, 0}, cc[6] = {0, 0, 0, 0, 0, 0}, ce[5] = {0, 0, 0, 0, 0};
     if (ptamd_host_bvh_trace(d.faces, d.n_faces, rays.data(), n, a.data(), ca) != PTAMD_OK ||
         ptamd_host_bvh4_trace(d.faces, d.n_faces, rays.data(), n, b.data(), cb) != PTAMD_OK ||
+        ptamd_host_bvh4q_trace(d.faces, d.n_faces, rays.data(), n, e.data(), ce) != PTAMD_OK ||
         ptamd_host_bvh8_trace(d.faces, d.n_faces, rays.data(), n, c.data(), cc) != PTAMD_OK) {
       std::fprintf(stderr, "host walk failed on %s: %s\n", path.c_str(), ptamd_get_last_error());
       std::exit(3);
     }
-    if (std::memcmp(a.data(), b.data(), a.size() * 4) != 0 || std::memcmp(a.data(), c.data(), a.size() * 4) != 0) {
-      std::fprintf(stderr, "the three host walks disagree on %s\n", path.c_str());
+    if (std::memcmp(a.data(), b.data(), a.size() * 4) != 0 || std::memcmp(a.data(), c.data(), a.size() * 4) != 0 ||
+        std::memcmp(a.data(), e.data(), a.size() * 4) != 0) {
+      std::fprintf(stderr, "the four host walks disagree on %s\n", path.c_str());
       std::exit(4);
     }
   }
