@@ -140,6 +140,7 @@ float frame_nb_inverse(float c)
   return 1.0f / c;
 }
 constexpr uint32_t kCompactMaxNodes = 896;   // 896 * 32 B = 28 KB of boxes below 0x8000 with 4 KB to spare for static LDS
+constexpr float kQuantisedMaxExtent = 1.0e8f;   // largest |coordinate| of a scene walked over quantised nodes (nodes4q / nodes8): see do_launch
 constexpr uint32_t kCompactMaxTris = 2047;   // a leaf's link code holds count << 11 | first triangle record in 15 bits (stage_scene)
 constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit); a 128-byte stride (one line per record) measured -0.7 % on the atrium
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
@@ -432,9 +433,13 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     size_t launch_lds = lds;
     if (restart && !resident) {
       // the eight-wide quantised form instead of the four-wide one (knob; not for the instrumented / time-stamp / far-origin instantiations)
-      const bool wide8 = ctx->wide8 && !stats && !p.brute_walk && !ctx->d_timeline && s.n_nodes8 != 0;
+      // the quantised node forms decode a plane as fma(plane, scale / d, fma(origin, 1 / d, -o / d)): with the 1e30 that stands in
+      // for 1 / 0 (axis-parallel rays) the inner fma stays finite for coordinates up to kQuantisedMaxExtent; beyond it the float
+      // nodes are walked, whose planes overflow one by one (an infinite slab distance is still a correct one)
+      const bool quantised_ok = s.extent <= kQuantisedMaxExtent;
+      const bool wide8 = ctx->wide8 && quantised_ok && !stats && !p.brute_walk && !ctx->d_timeline && s.n_nodes8 != 0;
       if (wide8) { p.nodes4 = s.nodes8; p.n_nodes4 = s.n_nodes8; p.wide8 = 1u; }
-      const bool wide4q = !wide8 && ctx->wide4q && !stats && !p.brute_walk && !ctx->d_timeline && s.nodes4q != nullptr;
+      const bool wide4q = !wide8 && ctx->wide4q && quantised_ok && !stats && !p.brute_walk && !ctx->d_timeline && s.nodes4q != nullptr;
       if (wide4q) { p.nodes4 = s.nodes4q; p.wide8 = 2u; }
       const uint32_t node_bytes = wide4q ? 64u : 128u;
       const uint32_t need = (wide8 ? 7u * s.depth8 : 3u * s.depth4) + 1u;   // a visit stacks all hit children but the nearest
@@ -1014,8 +1019,8 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   fill_far_table(p.far_table);
   p.small_det = 0u;                           // caller-supplied directions need not be unit vectors
   p.stack_lds_entries = 3u * s.depth4 + 1u;   // PTAMD_KERNEL_BVH_RESTART: the wide walk, whole stack in LDS
-  if (ctx->wide8 && s.n_nodes8 != 0) { p.nodes4 = s.nodes8; p.n_nodes4 = s.n_nodes8; p.wide8 = 1u; p.stack_lds_entries = 7u * s.depth8 + 1u; }
-  else if (ctx->wide4q && s.nodes4q != nullptr) { p.nodes4 = s.nodes4q; p.wide8 = 2u; }
+  if (ctx->wide8 && s.extent <= kQuantisedMaxExtent && s.n_nodes8 != 0) { p.nodes4 = s.nodes8; p.n_nodes4 = s.n_nodes8; p.wide8 = 1u; p.stack_lds_entries = 7u * s.depth8 + 1u; }
+  else if (ctx->wide4q && s.extent <= kQuantisedMaxExtent && s.nodes4q != nullptr) { p.nodes4 = s.nodes4q; p.wide8 = 2u; }
   float* d_rays = nullptr;
   int4* d_out = nullptr;
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));

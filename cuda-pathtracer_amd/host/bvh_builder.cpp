@@ -294,9 +294,11 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
     for (int k = 0; k < 3; ++k) {
       const float* v = &faces[i].vertices[k].x;
       for (int a = 0; a < 3; ++a) {
-        // NaN vertices would poison every ancestor box: keep them out of the bounds (such a
-        // face can never pass Moller-Trumbore either way)
-        if (v[a] == v[a]) { p.box.lo[a] = std::min(p.box.lo[a], v[a]); p.box.hi[a] = std::max(p.box.hi[a], v[a]); }
+        // NaN and infinite coordinates would poison every ancestor box (an infinite one gives the quantised nodes an origin of
+        // -inf, and every plane of such a node decodes to NaN): keep them out of the bounds.  Such a face can never pass
+        // Moller-Trumbore either way — an infinite edge makes the determinant +-inf or NaN, and with 1 / det = 0 or NaN the hit
+        // distance comes out NaN, which `t > 0` rejects (tests/test_gpu_parity.py: every kernel == the brute-force oracle on them).
+        if (std::fabs(v[a]) <= std::numeric_limits<float>::max()) { p.box.lo[a] = std::min(p.box.lo[a], v[a]); p.box.hi[a] = std::max(p.box.hi[a], v[a]); }
         if (std::fabs(v[a]) <= std::numeric_limits<float>::max()) extent = std::max(extent, std::fabs(v[a]));
         else all_finite = false;
       }
@@ -522,8 +524,9 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
         if (wide[w].child[c] < 0) continue;
         const BuildNode& cn = b.nodes[(size_t)wide[w].child[c]];
         for (int a = 0; a < 3; ++a) {
-          lo_c[c][a] = cn.box.lo[a] - (mq + std::fabs(cn.box.lo[a]) * 1e-6f);
-          hi_c[c][a] = cn.box.hi[a] + (mq + std::fabs(cn.box.hi[a]) * 1e-6f);
+          // (an infinite face is moved to the largest finite value: the node's origin and grid must stay finite)
+          lo_c[c][a] = std::max(-3.0e38f, std::min(3.0e38f, cn.box.lo[a] - (mq + std::fabs(cn.box.lo[a]) * 1e-6f)));
+          hi_c[c][a] = std::max(-3.0e38f, std::min(3.0e38f, cn.box.hi[a] + (mq + std::fabs(cn.box.hi[a]) * 1e-6f)));
           nlo[a] = std::min(nlo[a], lo_c[c][a]);
           nhi[a] = std::max(nhi[a], hi_c[c][a]);
         }
@@ -710,7 +713,10 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
             if (i < wn.n) {
               const Box& cb = b.nodes[(size_t)wn.child[i]].box;
               for (int a = 0; a < 3; ++a) {
-                const float off = (0.5f * cb.lo[a] + 0.5f * cb.hi[a]) - (0.5f * nb.lo[a] + 0.5f * nb.hi[a]);
+                float off = (0.5f * cb.lo[a] + 0.5f * cb.hi[a]) - (0.5f * nb.lo[a] + 0.5f * nb.hi[a]);
+                // (a box with an infinite or NaN face has no meaningful offset: it takes whatever slot is left.  A NaN here
+                // would win no comparison below and leave the assignment undefined.)
+                if (!(std::fabs(off) <= std::numeric_limits<float>::max())) off = 0.0f;
                 v += ((sl >> a) & 1) ? off : -off;
               }
             }
@@ -718,6 +724,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
           }
         float best[256];
         int8_t from[8][256];
+        std::memset(from, -1, sizeof from);
         for (int m = 0; m < 256; ++m) best[m] = -std::numeric_limits<float>::infinity();
         best[0] = 0.0f;
         // children are placed in index order: after i children the used-slot mask has i bits
@@ -732,7 +739,12 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
           }
         }
         int slot_of[8];
-        for (int i = 7, m = 255; i >= 0; --i) { slot_of[i] = from[i][m]; m &= ~(1 << slot_of[i]); }
+        for (int i = 7, m = 255; i >= 0; --i) {
+          int sl = from[i][m];
+          if (sl < 0 || !((m >> sl) & 1)) sl = __builtin_ctz((unsigned)m);   // (cannot happen with finite costs: any slot still free)
+          slot_of[i] = sl;
+          m &= ~(1 << sl);
+        }
         int placed[8];
         bool placed_leaf[8];
         for (int sl = 0; sl < 8; ++sl) { placed[sl] = -1; placed_leaf[sl] = false; }
@@ -763,8 +775,10 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
         if (wide[w].child[c] < 0) continue;
         const BuildNode& cn = b.nodes[(size_t)wide[w].child[c]];
         for (int a = 0; a < 3; ++a) {
-          lo_c[c][a] = cn.box.lo[a] - (m8 + std::fabs(cn.box.lo[a]) * 1e-6f);
-          hi_c[c][a] = cn.box.hi[a] + (m8 + std::fabs(cn.box.hi[a]) * 1e-6f);
+          // (an infinite face is moved to the largest finite value: the node's origin and grid must stay finite — with an
+          // origin of -inf every plane of the node decodes to NaN and the whole subtree is missed)
+          lo_c[c][a] = std::max(-3.0e38f, std::min(3.0e38f, cn.box.lo[a] - (m8 + std::fabs(cn.box.lo[a]) * 1e-6f)));
+          hi_c[c][a] = std::max(-3.0e38f, std::min(3.0e38f, cn.box.hi[a] + (m8 + std::fabs(cn.box.hi[a]) * 1e-6f)));
           nlo[a] = std::min(nlo[a], lo_c[c][a]);
           nhi[a] = std::max(nhi[a], hi_c[c][a]);
         }

@@ -355,7 +355,8 @@ int ptamd_host_bvh_trace(const ptamd_face* faces, uint32_t n_faces, const float*
 int ptamd_host_bvh4_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                           int32_t* out, uint64_t* counters);
 /* ... over the same four-wide nodes in their 64-byte form (8-bit child planes on a per-node grid), built with leaves of at most
- * three triangles as the device uses them.  counters as above. */
+ * three triangles as the device uses them.  counters as above.  The quantised forms (this one and the eight-wide one below) are
+ * for scenes whose finite coordinates stay within +-1e8: the library walks the float nodes beyond that. */
 int ptamd_host_bvh4q_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                            int32_t* out, uint64_t* counters);
 

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <random>
 #include <sstream>
 #include <string>
@@ -262,6 +263,50 @@ int main(int argc, char** argv)
       const std::string path = sdir + "/damaged" + ext[k];
       spit(path, b);
       exercise_image(path, it % 8 == 0);
+    }
+  }
+  // ---- 3. hostile geometry straight into the builder: a soup of triangles with one coordinate far out, infinite or NaN (such a
+  //         scene has boxes without a finite centre: round 3's slot assignment of the eight-wide nodes read an unset table entry
+  //         for them), degenerate faces, duplicates; every leaf size.  The four walks must agree on every ray.
+  {
+    std::uniform_real_distribution<float> u(-1.0f, 1.0f);
+    const float bad[] = { 3.0e9f, -3.0e9f, std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(),
+                          std::numeric_limits<float>::quiet_NaN(), 3.0e38f, -3.0e38f, 1.0e-30f, -9.0e7f, 9.0e7f };
+    for (int round = 0; round < 24; ++round) {
+      const uint32_t n = 20u + (uint32_t)(rng() % 120u);
+      std::vector<ptamd_face> faces(n);
+      std::memset(faces.data(), 0, n * sizeof(ptamd_face));
+      for (uint32_t i = 0; i < n; ++i) {
+        const float cx = 1.2f * u(rng), cy = 1.2f * u(rng), cz = 1.2f * u(rng);
+        for (int k = 0; k < 3; ++k) { faces[i].vertices[k].x = cx + 0.9f * u(rng); faces[i].vertices[k].y = cy + 0.9f * u(rng); faces[i].vertices[k].z = cz + 0.9f * u(rng); }
+      }
+      const uint32_t n_bad = 1u + (uint32_t)(rng() % 4u);
+      for (uint32_t k = 0; k < n_bad; ++k) (&faces[rng() % n].vertices[rng() % 3u].x)[rng() % 3u] = bad[rng() % (sizeof bad / sizeof *bad)];
+      if (round % 3 == 0) faces[rng() % n] = faces[rng() % n];                       // a duplicate
+      if (round % 4 == 0) faces[rng() % n].vertices[2] = faces[rng() % n].vertices[1];   // (nearly) degenerate
+      if (round % 5 == 0) for (int k = 0; k < 3; ++k) { ptamd_float3& v = faces[1].vertices[k]; v.x *= 1.0e9f; v.y *= 1.0e9f; v.z *= 1.0e9f; }
+      for (uint32_t max_leaf : { 1u, 3u, 4u, 15u }) {
+        ptamd::Bvh bvh;
+        if (ptamd::build_bvh(faces.data(), n, 1e-3f, max_leaf, bvh) != PTAMD_OK) { std::fprintf(stderr, "build_bvh refused a soup\n"); return 8; }
+      }
+      const uint32_t nr = 400;
+      std::vector<float> rays((size_t)nr * 6);
+      for (auto& v : rays) v = 2.0f * u(rng);
+      std::vector<int32_t> a((size_t)nr * 4), b4((size_t)nr * 4), q4((size_t)nr * 4), b8((size_t)nr * 4);
+      if (ptamd_host_bvh_trace(faces.data(), n, rays.data(), nr, a.data(), nullptr) != PTAMD_OK ||
+          ptamd_host_bvh4_trace(faces.data(), n, rays.data(), nr, b4.data(), nullptr) != PTAMD_OK ||
+          ptamd_host_bvh4q_trace(faces.data(), n, rays.data(), nr, q4.data(), nullptr) != PTAMD_OK ||
+          ptamd_host_bvh8_trace(faces.data(), n, rays.data(), nr, b8.data(), nullptr) != PTAMD_OK) return 9;
+      // (the quantised forms are for finite coordinates within +-1e8: the library walks the float nodes beyond that)
+      float extent = 0.0f;
+      for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k)
+          for (int ax = 0; ax < 3; ++ax) {
+            const float v = std::fabs((&faces[i].vertices[k].x)[ax]);
+            if (v <= std::numeric_limits<float>::max()) extent = std::max(extent, v);
+          }
+      const bool quantised_ok = extent <= 1.0e8f;
+      if (a != b4 || (quantised_ok && (a != q4 || a != b8))) { std::fprintf(stderr, "the host walks disagree on a hostile soup (round %d)\n", round); return 10; }
     }
   }
   std::printf("host_san: shipped inputs %lu loaded / %lu refused; damaged inputs %lu loaded / %lu refused; no sanitizer finding\n",

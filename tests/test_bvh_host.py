@@ -309,3 +309,25 @@ def test_quantised_four_wide_bvh_on_the_atrium(P, O, tmp_path):
     assert nodesq <= 1.15 * nodes4
     print("atrium: quantised four-wide nodes/ray %.2f (float form %.2f), triangles/ray %.2f (%.2f)"
           % (nodesq / len(rays), nodes4 / len(rays), trisq / len(rays), tris4 / len(rays)))
+
+
+def test_infinite_and_huge_coordinates(P, O):
+    """A coordinate that is infinite (either sign), NaN, or near the end of the float range: the builder keeps non-finite
+    coordinates out of the boxes (such a face can never be hit), every walk returns the brute-force record; the quantised forms
+    are for coordinates within +-1e8 (the library walks the float nodes beyond)."""
+    rng = np.random.default_rng(83)
+    base = random_soup(rng, 80, extent=1.2, size=0.9)
+    rays = random_rays(rng, 6000, extent=2.0)
+    rays[:30, 0] = 0.0
+    rays[30:60, 1] = -0.0
+    for bad in (np.inf, -np.inf, np.nan, 3.0e38, -3.0e38, 3.0e9, -9.0e7):
+        tris = base.copy()
+        tris[7, 1, 0] = np.float32(bad)
+        tris[11, 2, 2] = np.float32(bad)
+        hs = make_scene(P, tris)
+        want = O.intersect(lightless(O, P, hs), rays)
+        np.testing.assert_array_equal(P.host_bvh_trace(hs, rays)[0], want)
+        np.testing.assert_array_equal(P.host_bvh4_trace(hs, rays)[0], want)
+        if not np.isfinite(bad) or abs(bad) <= 1.0e8:
+            np.testing.assert_array_equal(P.host_bvh4q_trace(hs, rays)[0], want)
+            np.testing.assert_array_equal(P.host_bvh8_trace(hs, rays)[0], want)

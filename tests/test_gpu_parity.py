@@ -869,12 +869,14 @@ def test_one_texel_cubemaps(P, O, gpu_ctx):
 def test_scenes_outside_the_short_reciprocal_range(P, O, gpu_ctx):
     """The restart kernel divides by the Moller-Trumbore determinant with a 7-instruction exact reciprocal only where the
     launcher can bound the determinant (all vertices finite and <= 1e8, ptamd_api.cpp: small_det).  One far vertex (3e9), an
-    infinite one and a NaN one switch it off: every variant still renders the oracle's pixels."""
+    infinite one (either sign: infinite coordinates stay out of the boxes, a face with one can never be hit), a NaN one and one
+    near the end of the float range switch it off: every variant still renders the oracle's pixels."""
     rng = np.random.default_rng(77)
     cube = synthetic_cubemap(rng, 2)
     lights = [((0.0, 0.5, 1.0), (1.0, 0.9, 0.8), 4.0, 0.8)]
     base = random_soup(rng, 60, extent=1.2, size=0.9)
-    for name, bad in (("far vertex", 3.0e9), ("infinite vertex", np.inf), ("nan vertex", np.nan)):
+    for name, bad in (("far vertex", 3.0e9), ("infinite vertex", np.inf), ("nan vertex", np.nan),
+                      ("minus infinite vertex", -np.inf), ("vertex at -3e38", -3.0e38)):
         tris = base.copy()
         tris[7, 1, 0] = np.float32(bad)          # one coordinate of one face
         if name == "far vertex":
