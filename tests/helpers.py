@@ -11,11 +11,11 @@ def make_scene(P, tris, normals=None, uvs=None, material_ids=None, materials=Non
     faces = np.zeros(n, dtype=P.FACE_DTYPE)
     faces["vertices"] = tris
     if normals is None:
-        e1 = tris[:, 1] - tris[:, 0]
-        e2 = tris[:, 2] - tris[:, 0]
-        nn = np.cross(e1, e2)
-        ln = np.linalg.norm(nn, axis=1, keepdims=True)
-        with np.errstate(all="ignore"):   # (degenerate and NaN triangles are test inputs)
+        with np.errstate(all="ignore"):   # (degenerate, NaN, infinite and huge triangles are test inputs)
+            e1 = tris[:, 1] - tris[:, 0]
+            e2 = tris[:, 2] - tris[:, 0]
+            nn = np.cross(e1, e2)
+            ln = np.linalg.norm(nn, axis=1, keepdims=True)
             nn = np.where(ln > 0, nn / np.maximum(ln, 1e-30), 0).astype(np.float32)
         normals = np.repeat(nn[:, None, :], 3, axis=1)
     faces["normals"] = np.asarray(normals, dtype=np.float32)
