@@ -144,7 +144,7 @@ constexpr float kQuantisedMaxExtent = 1.0e8f;   // largest |coordinate| of a sce
 constexpr uint32_t kCompactMaxTris = 2047;   // a leaf's link code holds count << 11 | first triangle record in 15 bits (stage_scene)
 constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit); a 128-byte stride (one line per record) measured -0.7 % on the atrium
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
-constexpr uint32_t kMaxLeaf = 3;   // 3 beats 4 by 1.2 % now that a box test costs a third of a triangle test (scripts/gpu_knobs.sh)
+constexpr uint32_t kMaxLeaf = 2;   // 2 / 3 / 4 = 10902 / 10839 / 10160 Msamples/s on the headline now that a box test costs 16 VALU and a triangle test ~67 (scripts/gpu_r3_leaf2.sh: every bench configuration >= leaves of three)
 constexpr uint32_t kTicketRing = 1024;
 constexpr size_t kMaxScratchStreams = 16;   // sample scratches kept per context (one per stream that batches frames)
 #ifndef PT_PERSISTENT_THREADS

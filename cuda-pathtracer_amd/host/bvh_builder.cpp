@@ -1138,7 +1138,7 @@ extern "C" int ptamd_host_bvh8_trace(const ptamd_face* faces, uint32_t n_faces, 
 {
   if ((n_faces && !faces) || (n && (!rays || !out))) { ptamd::set_error("ptamd_host_bvh8_trace: null argument"); return PTAMD_ERR_ARG; }
   ptamd::Bvh bvh;
-  int rc = ptamd::build_bvh(faces, n_faces, 1e-3f, 3, bvh);
+  int rc = ptamd::build_bvh(faces, n_faces, 1e-3f, 2, bvh);
   if (rc != PTAMD_OK) return rc;
   for (uint32_t i = 0; i < n; ++i) {
     ptamd::HostHit h;
@@ -1178,7 +1178,7 @@ extern "C" int ptamd_host_bvh4q_trace(const ptamd_face* faces, uint32_t n_faces,
 {
   if ((n_faces && !faces) || (n && (!rays || !out))) { ptamd::set_error("ptamd_host_bvh4q_trace: null argument"); return PTAMD_ERR_ARG; }
   ptamd::Bvh bvh;
-  int rc = ptamd::build_bvh(faces, n_faces, 1e-3f, 3, bvh);
+  int rc = ptamd::build_bvh(faces, n_faces, 1e-3f, 2, bvh);
   if (rc != PTAMD_OK) return rc;
   for (uint32_t i = 0; i < n; ++i) {
     ptamd::HostHit h;

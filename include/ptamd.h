@@ -355,13 +355,13 @@ int ptamd_host_bvh_trace(const ptamd_face* faces, uint32_t n_faces, const float*
 int ptamd_host_bvh4_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                           int32_t* out, uint64_t* counters);
 /* ... over the same four-wide nodes in their 64-byte form (8-bit child planes on a per-node grid), built with leaves of at most
- * three triangles as the device uses them.  counters as above.  The quantised forms (this one and the eight-wide one below) are
+ * two triangles as the device uses them.  counters as above.  The quantised forms (this one and the eight-wide one below) are
  * for scenes whose finite coordinates stay within +-1e8: the library walks the float nodes beyond that. */
 int ptamd_host_bvh4q_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                            int32_t* out, uint64_t* counters);
 
 /* ... and for the eight-wide form with quantised child boxes (one 128-byte line per node: origin, per-axis power-of-two
- * scale, 8-bit planes), built with leaves of at most three triangles as the device uses it.  counters (optional, 6 words):
+ * scale, 8-bit planes), built with leaves of at most two triangles as the device uses it.  counters (optional, 6 words):
  * [0] += nodes visited, [1] += triangles tested, [2] = depth, [3] / [4] += visits to the first 73 / 585 nodes, [5] = node count. */
 int ptamd_host_bvh8_trace(const ptamd_face* faces, uint32_t n_faces, const float* rays, uint32_t n,
                           int32_t* out, uint64_t* counters);
