@@ -33,7 +33,9 @@ for f in glob.glob(os.path.join(out_dir, "pass*", "**", "*counter_collection.csv
             bools = [t for t in targs if t in ("true", "false")]
             if len(bools) >= 2 and bools[1] == "true":      # <.., LDS_RESIDENT, STATS, ..>: skip instrumented launches
                 continue
-            if "pt_megakernel_restart" in nm and len(targs) >= 2 and targs[1] != "0":   # <LDS_RESIDENT, VARIANT>: 0 = the shipped kernel
+            # <LDS_RESIDENT, VARIANT>: 0 = the shipped kernel, 4 / 5 = the uninstrumented walks of big scenes (eight-wide, 64-byte four-wide);
+            # 1 counters, 2 time stamps, 3 every-triangle search are not what a profile is about
+            if "pt_megakernel_restart" in nm and len(targs) >= 2 and targs[1] in ("1", "2", "3"):
                 continue
             want = {"bvh": "pt_megakernel<", "brute": "pt_megakernel<", "persistent": "pt_megakernel_persistent<",
                     "blockwise": "pt_megakernel_blockwise<", "split": "pt_megakernel_split<", "restart": "pt_megakernel_restart<"}.get(kernel)
