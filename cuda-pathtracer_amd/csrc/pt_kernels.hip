@@ -1206,16 +1206,29 @@ struct Stack4 {
 #define PT_RS4_WAVES_PER_EU 4   /* measured on the atrium (leaf records fetched in one batch): 4 / 5 / 6 waves per SIMD = 1069 / 954 / 798 Msamples/s (5 and 6 spill) */
 #endif
 
+// The LDS parts of the walk (stack column, treelet) are addressed through pointers that SAY they are LDS: with generic pointers the
+// compiler folds "LDS or global" into one selected address and issues FLAT loads and stores for both (every pop a flat_load through
+// the texture path, every push a ds_write of the reference plus a flat_store of the distance; the node fetch four flat loads).
+// (HIP's uint2 / uint4 / float4 are classes whose assignment wants generic references: the LDS-typed accesses use the native
+// vector types)
+typedef uint32_t pt_u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t pt_u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) pt_u2v* LdsU2;
+typedef const __attribute__((address_space(3))) pt_u4v* LdsCU4;
+PT_DEV LdsU2 stack4_lds(const Stack4& s) { return (LdsU2)(uintptr_t)(uint32_t)(uintptr_t)s.lds; }
+PT_DEV LdsCU4 treelet_lds(const Stack4& s) { return (LdsCU4)(uintptr_t)(uint32_t)(uintptr_t)s.top; }
+PT_DEV uint4 lds_u4(LdsCU4 q) { const pt_u4v v = *q; return make_uint4(v.x, v.y, v.z, v.w); }
+PT_DEV float4 lds_f4(LdsCU4 q) { const pt_u4v v = *q; return make_float4(u_as_f(v.x), u_as_f(v.y), u_as_f(v.z), u_as_f(v.w)); }
+
 PT_DEV void stack4_write(const Stack4& s, uint32_t k, uint32_t ref, float tnear)
 {
-  const uint2 e = make_uint2(ref, f_as_u(tnear));
-  if (k < s.lds_entries) s.lds[k * 64u] = e;
-  else s.spill[(size_t)(k - s.lds_entries) * 64u] = e;
+  if (k < s.lds_entries) { pt_u2v e; e.x = ref; e.y = f_as_u(tnear); stack4_lds(s)[k * 64u] = e; }
+  else s.spill[(size_t)(k - s.lds_entries) * 64u] = make_uint2(ref, f_as_u(tnear));
 }
 
 PT_DEV uint2 stack4_read(const Stack4& s, uint32_t k)
 {
-  if (k < s.lds_entries) return s.lds[k * 64u];
+  if (k < s.lds_entries) { const pt_u2v e = stack4_lds(s)[k * 64u]; return make_uint2(e.x, e.y); }
   return s.spill[(size_t)(k - s.lds_entries) * 64u];
 }
 
@@ -1240,10 +1253,10 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
   float4 lx, ly, lz, hx, hy, hz;
   uint4 refs, ord;
   if (cur < stk.top_n) {
-    const float4* q = stk.top + cur * 8u;
-    lx = q[0]; ly = q[1]; lz = q[2]; hx = q[3]; hy = q[4]; hz = q[5];
-    refs = *reinterpret_cast<const uint4*>(q + 6);
-    ord = *reinterpret_cast<const uint4*>(q + 7);
+    const LdsCU4 q = treelet_lds(stk) + cur * 8u;
+    lx = lds_f4(q); ly = lds_f4(q + 1); lz = lds_f4(q + 2); hx = lds_f4(q + 3); hy = lds_f4(q + 4); hz = lds_f4(q + 5);
+    refs = lds_u4(q + 6);
+    ord = lds_u4(q + 7);
   } else {
     const float4* q = nodes4 + (size_t)cur * 8u;
     lx = q[0]; ly = q[1]; lz = q[2]; hx = q[3]; hy = q[4]; hz = q[5];
@@ -1334,8 +1347,8 @@ PT_DEV uint32_t walk8_visit(const float4* nodes8, const Stack4& stk, const Walk&
 {
   uint4 hd, ra, rb, pa, pb, pc;
   if (cur < stk.top_n) {
-    const uint4* q = reinterpret_cast<const uint4*>(stk.top) + cur * 8u;
-    hd = q[0]; ra = q[1]; rb = q[2]; pa = q[3]; pb = q[4]; pc = q[5];
+    const LdsCU4 q = treelet_lds(stk) + cur * 8u;
+    hd = lds_u4(q); ra = lds_u4(q + 1); rb = lds_u4(q + 2); pa = lds_u4(q + 3); pb = lds_u4(q + 4); pc = lds_u4(q + 5);
   } else {
     const uint4* q = reinterpret_cast<const uint4*>(nodes8) + (size_t)cur * 8u;
     hd = q[0]; ra = q[1]; rb = q[2]; pa = q[3]; pb = q[4]; pc = q[5];
@@ -1396,8 +1409,8 @@ PT_DEV uint32_t walk4q_visit(const float4* nodesq, const Stack4& stk, const Walk
 {
   uint4 hd, rf, pa, pb;
   if (cur < stk.top_n) {
-    const uint4* q = reinterpret_cast<const uint4*>(stk.top) + cur * 4u;
-    hd = q[0]; rf = q[1]; pa = q[2]; pb = q[3];
+    const LdsCU4 q = treelet_lds(stk) + cur * 4u;
+    hd = lds_u4(q); rf = lds_u4(q + 1); pa = lds_u4(q + 2); pb = lds_u4(q + 3);
   } else {
     const uint4* q = reinterpret_cast<const uint4*>(nodesq) + (size_t)cur * 4u;
     hd = q[0]; rf = q[1]; pa = q[2]; pb = q[3];

@@ -107,7 +107,7 @@ struct ptamd_context {
   // a host that simply calls raytrace() again without synchronising (gpu_processor.cpp:365-386 does not).
   hipStream_t internal[2] = { nullptr, nullptr };
   bool overlap = true;                    // PTAMD_OVERLAP=0 (tuning): everything on the caller's stream
-  bool wide4q = true;                     // big scenes walk the 64-byte quantised four-wide nodes (atrium 1438 -> 1478 Msamples/s); PTAMD_WIDE4Q=0 (tuning): the float nodes
+  bool wide4q = false;                    // PTAMD_WIDE4Q=1 (tuning): big scenes walk the 64-byte quantised four-wide nodes instead of the float ones (ahead by 2.8 % while the walk's LDS accesses went out as FLAT instructions, level since they are LDS instructions: profiles/r03_notes.md)
   bool wide8 = false;                     // PTAMD_WIDE8=1 (tuning): big scenes walk the eight-wide quantised nodes (measured 8 % slower: DESIGN.md §4)
   unsigned long long* d_timeline = nullptr;   // ptamd_set_timeline: 4 time stamps per wave of the restart kernel
   uint32_t timeline_waves = 0;

@@ -427,10 +427,9 @@ def test_eight_wide_quantised_walk_on_the_device(P, O, monkeypatch):
 
 @pytest.mark.parametrize("quantised", ["1", "0"])
 def test_quantised_four_wide_walk_on_the_device(P, O, monkeypatch, quantised):
-    """(quantised = "0": the same checks on the float nodes, which the instrumented builds and PTAMD_WIDE4Q=0 still walk.)
+    """(quantised = "0": the same checks on the float nodes, the default.)
     The four-wide tree in 64-byte quantised nodes (Bvh::nodes4q: float origin, per-axis power-of-two scale, 8-bit planes, the
-    order of four octants stored and read inverted for the opposite four — the default walk of scenes that do not fit in LDS):
-    nearest-hit records == brute-force
+    order of four octants stored and read inverted for the opposite four; PTAMD_WIDE4Q=1): nearest-hit records == brute-force
     oracle (zeros of either sign in the directions), rendered frames == oracle with the stack in LDS and mostly in the global
     slab and with / without the LDS treelet, a batched launch == consecutive launches."""
     import torch
