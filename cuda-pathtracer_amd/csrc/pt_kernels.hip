@@ -1202,6 +1202,9 @@ struct Stack4 {
 #define PT_RS4_THREADS 1024     /* workgroup size of the wide-walk instantiation: ONE workgroup per CU, so one copy of the LDS treelet
                                    (256 / 512 / 1024 threads: atrium 1177 / 1233 / 1278, tessellated indoor 2868 / 2966 / 3081 Msamples/s) */
 #endif
+#ifndef PT_PUSH_BRANCHFREE
+#define PT_PUSH_BRANCHFREE 1    /* four-wide float walk: hit children pushed without branches when the LDS part of the stack has room */
+#endif
 #ifndef PT_RS4_WAVES_PER_EU
 #define PT_RS4_WAVES_PER_EU 4   /* measured on the atrium (leaf records fetched in one batch): 4 / 5 / 6 waves per SIMD = 1069 / 954 / 798 Msamples/s (5 and 6 spill) */
 #endif
@@ -1298,6 +1301,26 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
   const uint32_t nhit = (uint32_t)__builtin_popcount(hit);
   const uint32_t ref[4] = { refs.x, refs.y, refs.z, refs.w };
   uint32_t next = PT_NONE;
+#if PT_PUSH_BRANCHFREE
+  // Usual case, decided for the whole wave: four more entries fit into the LDS part of every lane's stack.  Then every child is
+  // written without a branch — a hit child that is not the nearest to slot sp + rank, the others to slot sp + 3, which lies at or
+  // above the new top of the stack (at most three are pushed) and is free.
+  if (__ballot(sp + 4u > stk.lds_entries) == 0ull) {
+    const LdsU2 col = stack4_lds(stk);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool h = ((hit >> c) & 1u) != 0u;
+      const uint32_t rank = (uint32_t)__builtin_popcount(hit & (order >> (4 * c)) & 0xFu);
+      const bool nearest = h && rank + 1u == nhit;
+      next = nearest ? ref[c] : next;
+      pt_u2v e;
+      e.x = ref[c]; e.y = f_as_u(tn[c]);
+      col[(sp + ((h && !nearest) ? rank : 3u)) * 64u] = e;
+    }
+    sp += nhit - 1u;
+    return next;
+  }
+#endif
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if ((hit >> c) & 1u) {
