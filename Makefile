@@ -8,13 +8,14 @@ ARCH     ?= gfx950
 #   shuffles and spills; scalar code is 6.8 % faster (scripts/gpu_flags.sh)
 HIPFLAGS := $(EXTRA_HIPFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -Iinclude -I$(PKG)/host -I$(PKG)/csrc \
             -Wall -Wextra -Wno-unused-parameter
-# identity of the device code: the sources every kernel is compiled from + the flags (profiles/pmc_latest.json carries the id of
-# the build its counters were collected on; bench.py refuses to price a roofline with counters of another build)
-DEVICE_SRCS := $(PKG)/csrc/pt_kernels.hip $(PKG)/csrc/pt_device.h $(PKG)/csrc/pt_launch.h
-BUILD_ID := $(shell (cat $(DEVICE_SRCS); echo "$(HIPFLAGS)") | sha256sum | cut -c1-16)
 LIB      := $(PKG)/libptamd.so
 SRCS     := $(PKG)/csrc/pt_kernels.hip $(PKG)/csrc/ptamd_api.cpp $(PKG)/host/scene_loader.cpp $(PKG)/host/bvh_builder.cpp $(PKG)/host/image_decode.cpp $(PKG)/host/image_png.cpp $(PKG)/host/image_resize.cpp
 HDRS     := include/ptamd.h $(PKG)/host/ptamd_internal.h $(PKG)/csrc/pt_device.h $(PKG)/csrc/pt_launch.h
+# identity of the build: EVERY source and header the library is compiled from + the flags, in this order (the host half decides what
+# the device executes too: leaf size, launch geometry and slab sizing in ptamd_api.cpp, the tree's shape in bvh_builder.cpp).
+# profiles/pmc_*.json carry the id of the build their counters were collected on; bench.py refuses to price a roofline with counters
+# of another build.   Recompute: (cat $(SRCS) $(HDRS); echo "$(HIPFLAGS)") | sha256sum | cut -c1-16
+BUILD_ID := $(shell (cat $(SRCS) $(HDRS); echo "$(HIPFLAGS)") | sha256sum | cut -c1-16)
 
 ORACLE   := oracle/libpt_oracle.so
 

@@ -1265,14 +1265,6 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
     lx = q[0]; ly = q[1]; lz = q[2]; hx = q[3]; hy = q[4]; hz = q[5];
     refs = *reinterpret_cast<const uint4*>(q + 6);
     ord = *reinterpret_cast<const uint4*>(q + 7);
-#ifdef PT_EXPERIMENT_DUP_LOADS   /* scratch experiment: how much do extra tag lookups of an L1-resident line cost? */
-    {
-      const volatile float4* v = reinterpret_cast<const volatile float4*>(q);
-      float acc = 0.f;
-      for (int i = 0; i < PT_EXPERIMENT_DUP_LOADS; ++i) { const float4 t = const_cast<const float4&>(v[i & 7]); acc += t.x; }
-      if (acc == 1.2345e-30f) lx.x = acc;
-    }
-#endif
   }
   // (references and order words are needed last, but fetched with the boxes: one round trip per visit)
   asm volatile("" : "+v"(refs.x), "+v"(refs.y), "+v"(refs.z), "+v"(refs.w), "+v"(ord.x), "+v"(ord.y), "+v"(ord.z), "+v"(ord.w));
@@ -2487,7 +2479,8 @@ hipError_t resolve_kernels()
     reinterpret_cast<const void*>(pt_megakernel<2, false, false, PT_TILE_THREADS>),
     reinterpret_cast<const void*>(pt_resolve_kernel), reinterpret_cast<const void*>(pt_resolve_kernel4),
     reinterpret_cast<const void*>(pt_trace_rays_kernel<1>), reinterpret_cast<const void*>(pt_trace_rays_kernel<2>),
-    reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<false>), reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<true>),
+    reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<0>), reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<1>),
+    reinterpret_cast<const void*>(pt_trace_rays_wide_kernel<2>),
   };
   for (const void* fn : fns) {
     hipFuncAttributes attr;

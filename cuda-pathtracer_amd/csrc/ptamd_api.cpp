@@ -712,13 +712,15 @@ void ptamd_destroy(ptamd_context* ctx)
 {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  // before anything is freed: megakernels may still be running on the non-blocking internal streams (they read the scene tables
+  // and the ticket heads), resolve passes on the callers' streams
+  (void)hipDeviceSynchronize();
   for (auto& s : ctx->scenes) free_scene(s);
   for (auto& c : ctx->cubemaps) (void)hipFree(c.faces);
   (void)hipFree(ctx->d_stats);
   (void)hipFree(ctx->d_gamma);
   (void)hipFree(ctx->d_tickets);
   (void)hipFree(ctx->d_heads);
-  (void)hipDeviceSynchronize();   // megakernels on the internal streams included
   for (auto& c : ctx->sample_scratch) free_scratch(c);
   for (hipStream_t is : ctx->internal) if (is) (void)hipStreamDestroy(is);
   (void)hipFree(ctx->d_timeline);

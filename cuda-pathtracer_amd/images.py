@@ -3,11 +3,12 @@ stbi_loadf (material_loader.cpp:97, gpu_processor.cpp:99): 8-bit channels become
 `pow(v / 255, 2.2)` for colour channels and `v / 255` for an alpha channel (stb_image.h: the
 ldr-to-hdr conversion).
 
-`load_image` / `load_image8` call libptamd's built-in JPEG decoder (host/image_decode.cpp), whose
-pixels are bit-identical to stb_image's; it is what `HostScene.load` uses by default.
-`pil_image_loader` is an optional provider for formats the built-in decoder does not read (PNG ...):
-it reproduces the float contract on top of PIL, but PIL's JPEG decoder (libjpeg) differs from stb's
-by an LSB here and there, so it is not used for parity runs."""
+`load_image` / `load_image8` call libptamd's built-in decoders — JPEG (host/image_decode.cpp), PNG
+(host/image_png.cpp) and Radiance HDR —, whose pixels are bit-identical to stb_image 2.16's
+(tests/test_ref_thirdparty.py); they are what `HostScene.load` uses by default.
+`pil_image_loader` is an optional provider for formats the built-in decoders do not read (BMP, TGA,
+GIF ...): it reproduces the float contract on top of PIL, but PIL's JPEG decoder (libjpeg) differs
+from stb's by an LSB here and there, so it is not used for parity runs."""
 from __future__ import annotations
 
 import ctypes as C

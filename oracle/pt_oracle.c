@@ -44,6 +44,24 @@ _Static_assert(sizeof(or_camera) == 64, "Camera is 64 B (SD:123-133)");
 
 #define OR_PI_D 3.14159265358979323846 /* M_PI of <math.h> (double), RT:106, PP:55 */
 
+/* ------------------------------------------------------------------ study instantiations (tests/test_tolerance_study.py)
+ * The DEFAULT build (no macro, -ffp-contract=off) is the oracle.  The switches below build stand-ins for what the reference's
+ * own binary may compute differently — it is built with `nvcc -O2` and nothing else (CMakeLists.txt:20-22), i.e. --fmad=true,
+ * with libdevice's cosf/sinf/powf/tanf and the fast intrinsics __cosf/__sinf/__fdividef — so that the size of that gap can be
+ * stated (scripts/tolerance_study.py).  None of them is "the reference": they bound how far two faithful
+ * builds of this integrator drift apart.
+ *   -ffp-contract=fast     (compiler flag) a*b+c contracted to fma wherever the compiler likes, as nvcc's default permits
+ *   -DOR_STUDY_LIBM        glibc's sinf/cosf/powf in place of or_sincosf/or_powf (another <= 2 ulp implementation, as libdevice is)
+ *   -DOR_STUDY_FASTINTR    RT:111-112,122's __cosf/__sinf as values with an absolute error of up to 2^-22 (documented bound of
+ *                          sin.approx.f32 on [-pi, pi]: 2^-21.41), and __fdividef(a, b) (IX:113, RT:206) as a * (1 / b)
+ *                          (two roundings; documented bound 2 ulp) */
+#ifdef OR_STUDY_FASTINTR
+static inline float or_fast_trig(double v) { return (float)(rint(v * 2097152.0) / 2097152.0); }   /* multiples of 2^-21 */
+#define OR_FDIVIDEF(a, b) ((a) * (1.0f / (b)))
+#else
+#define OR_FDIVIDEF(a, b) ((a) / (b))
+#endif
+
 /* ------------------------------------------------------------------ CM.h float3 ops */
 static inline or_f3 f3(float x, float y, float z) { or_f3 r = { x, y, z }; return r; }
 static inline or_f3 f3s(float s) { return f3(s, s, s); }                                   /* CM:139 */
@@ -87,6 +105,10 @@ static inline float clampf(float f, float a, float b) { return fmaxf_d(a, fminf_
  * [-pi/4, pi/4].  Stands for CUDA's cosf/sinf (PP:60) and __cosf/__sinf (RT:122). */
 void or_sincosf(float x, float* s, float* c)
 {
+#ifdef OR_STUDY_LIBM
+  *s = sinf(x); *c = cosf(x);
+  return;
+#endif
   const float two_over_pi = 0x1.45f306p-1f;
   const float pio2_hi = 0x1.921fb6p+0f;
   const float pio2_lo = -0x1.777a5cp-25f;
@@ -113,6 +135,9 @@ static inline uint64_t or_double_to_bits(double d) { uint64_t b; memcpy(&b, &d, 
 /* powf computed in binary64: 2^(y*log2(x)).  Stands for CUDA's powf (RT:163, CM:1750). */
 float or_powf(float xf, float yf)
 {
+#ifdef OR_STUDY_LIBM
+  return powf(xf, yf);
+#endif
   if (yf == 0.0f || xf == 1.0f) return 1.0f;
   if (xf != xf || yf != yf) return NAN;
   double x = (double)xf, y = (double)yf;
@@ -353,7 +378,7 @@ static int intersect_triangle(const or_face* face, or_f3* out_normal, or_f2* out
   float det = dot(v0v1, p_vec);
   if ((double)det < 0.0000001) /* IX:110: double literal */
     return 0;
-  float inv_det = 1.0f / det; /* __fdividef(1.f, det) */
+  float inv_det = OR_FDIVIDEF(1.0f, det); /* __fdividef(1.f, det) */
   or_f3 t_vec = sub(ray->origin, face->vertices[0]);
   float u = dot(t_vec, p_vec) * inv_det;
   if (u < 0 || u > 1)
@@ -566,7 +591,11 @@ static or_f3 radiance(or_ray* r, const or_scene* sc, uint32_t* rng, int is_stati
         or_f3 u = normalize(cross(axis, oriented_normal));
         or_f3 v = cross(oriented_normal, u);
         float sphi, cphi;
+#ifdef OR_STUDY_FASTINTR
+        sphi = or_fast_trig(sin((double)phi)); cphi = or_fast_trig(cos((double)phi)); /* __sinf / __cosf (RT:111-112,122) */
+#else
         or_sincosf(phi, &sphi, &cphi);
+#endif
         or_f3 d = normalize(add(add(muls(muls(v, sin_t), cphi), muls(muls(u, sphi), sin_t)),
                                 muls(oriented_normal, cos_t)));
         r->origin = add(r->origin, muls(r->dir, inter.dist));
@@ -610,7 +639,7 @@ static or_f3 radiance(or_ray* r, const or_scene* sc, uint32_t* rng, int is_stati
     float p = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z)); /* CUDA fmaxf: NaN-ignoring */
     if (r1 > p && b > 1)
       return acc;
-    throughput = muls(throughput, 1.0f / p); /* __fdividef(1.0f, p) */
+    throughput = muls(throughput, OR_FDIVIDEF(1.0f, p)); /* __fdividef(1.0f, p) */
   }
   return acc;
 }

@@ -73,7 +73,22 @@ def load() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    lib = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def build_variant(out_path: str, flags=()) -> C.CDLL:
+    """A STUDY instantiation of the same source (pt_oracle.c: OR_STUDY_*, -ffp-contract=fast): what another faithful build of
+    the integrator may compute.  Never the oracle; used by scripts/tolerance_study.py and tests/test_tolerance_study.py."""
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    cmd = ["gcc", "-O2", "-std=c11", "-mfma", "-fPIC", "-shared", "-o", out_path, os.path.join(_HERE, "pt_oracle.c"), "-lm", "-lpthread"]
+    if not any(f.startswith("-ffp-contract") for f in flags):
+        cmd.insert(1, "-ffp-contract=off")
+    subprocess.check_call(cmd[:1] + list(flags) + cmd[1:])
+    return _bind(C.CDLL(out_path))
+
+
+def _bind(lib: C.CDLL) -> C.CDLL:
     lib.or_wang_hash.restype = C.c_uint32
     lib.or_wang_hash.argtypes = [C.c_uint32]
     lib.or_xorwow_init.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
@@ -102,7 +117,6 @@ def load() -> C.CDLL:
                               C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p,
                               C.c_int32]
     lib.or_last_stats.argtypes = [C.POINTER(C.c_uint64)]
-    _lib = lib
     return lib
 
 
@@ -161,10 +175,11 @@ def wang_hash(a: int) -> int:
 
 def render(scene: OracleScene, cam: Camera, width: int, height: int, spp: int = 1, bounces: int = 3,
            moved: bool = False, post_id: int = 0, rows=None, nthreads: int = 0, first_frame: int = 1,
-           accum: np.ndarray | None = None):
+           accum: np.ndarray | None = None, lib: C.CDLL | None = None):
     """N-spp render = N static launches with frame seeds first_frame.. (raytrace.cu:296-300).
-    Returns (accum float32[H,W,3] in the reference's row-flipped order, rgba uint8[H,W,4])."""
-    lib = load()
+    Returns (accum float32[H,W,3] in the reference's row-flipped order, rgba uint8[H,W,4]).
+    lib: a study instantiation from build_variant() instead of the oracle."""
+    lib = lib or load()
     if nthreads <= 0:
         nthreads = os.cpu_count() or 1
     y0, y1 = rows if rows is not None else (0, height)

@@ -28,4 +28,5 @@ for SET in "${SETS[@]}"; do
   rocprofv3 --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --kernel $KERNEL "$@" > $OUT/pass$i.log 2>&1
   echo "pass $i ($SET) rc=$?"
 done
-python3 $R/scripts/summarize_pmc.py $OUT $KERNEL $R/gpurun_out/pmc_latest.json "$@" > $R/gpurun_out/pmc_summary_$KERNEL.json
+# PMC_OUT: name of the small record bench.py reads (default pmc_latest.json = the headline; other workloads: pmc_atrium.json, ...)
+python3 $R/scripts/summarize_pmc.py $OUT $KERNEL $R/gpurun_out/${PMC_OUT:-pmc_latest.json} "$@" > $R/gpurun_out/pmc_summary_$KERNEL.json

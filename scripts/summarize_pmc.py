@@ -84,6 +84,15 @@ rec = {"build_id": _native.load().ptamd_build_id().decode(), "kernel": kernel, "
        "gui_active_cycles_per_launch": None if "GRBM_GUI_ACTIVE" not in res else res["GRBM_GUI_ACTIVE"] / 8.0,
        "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
        "hbm_bytes_per_launch": None if fetch_kb is None or write_kb is None else fetch_kb * 1024 * 2 + write_kb * 1024,
+       # walks served from the caches (PMC_EXTRA=l1x passes): L1 -> L2 line requests and their mean latency, L2 hits / misses,
+       # share of wave cycles spent waiting
+       "vmem_rd_insts_per_launch": res.get("SQ_INSTS_VMEM_RD"), "l1_accesses_per_launch": res.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
+       "l1_to_l2_requests_per_launch": res.get("TCP_TCC_READ_REQ_sum"),
+       "l1_to_l2_mean_latency_cycles": None if not res.get("TCP_TCC_READ_REQ_sum") else res.get("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / res["TCP_TCC_READ_REQ_sum"],
+       "l2_hits_per_launch": res.get("TCC_HIT_sum"), "l2_misses_per_launch": res.get("TCC_MISS_sum"),
+       "wait_any_share_of_wave_cycles": d.get("SQ_WAIT_ANY/SQ_WAVE_CYCLES"),
+       "lds_bank_conflict_share_of_lds_cycles": d.get("lds_bank_conflict_share_of_lds_cycles"),
+       "mean_waves_resident": d.get("mean_waves_resident(SQ_WAVE_CYCLES/SQ_BUSY_CYCLES)"),
        "source": "rocprofv3 --pmc passes (scripts/collect_pmc.sh), per-dispatch averages over the un-instrumented "
                  "megakernel launches of `bench.py --no-extra`; FETCH_SIZE x2 (gfx950), WRITE_SIZE exact"}
 json.dump(rec, open(latest, "w"), indent=1)
