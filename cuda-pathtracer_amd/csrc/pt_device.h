@@ -322,6 +322,7 @@ struct KParams {
   uint32_t walk_min4;
   uint32_t wide8;                 // which form `nodes4` holds: 0 four-wide float nodes, 1 the eight-wide quantised form (PTAMD_WIDE8 knob), 2 four-wide 64-byte quantised nodes
   uint32_t far_table[16];         // eight-wide walk: for ray octant o, byte c of the pair [2 o], [2 o + 1] = the slots visited after slot c
+  uint32_t xcd_regions;           // restart kernel: != 0: tickets map to tiles through XCD-local regions (pt_kernels.hip: region_tile); needs n_static % 8 == 0 and tiles_per_ticket == 1
   uint32_t brute_walk;            // restart kernel: the launch wants the instantiation that tests every triangle record instead of walking the tree (far origin)
   unsigned long long* timeline;   // restart kernel: != nullptr selects the instantiation that records 4 time stamps per wave (ptamd_set_timeline)
 };

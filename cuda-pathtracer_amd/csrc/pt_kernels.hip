@@ -136,6 +136,7 @@ struct Walk {
   uint32_t link_off; // dword offset of this ray's octant inside a node's miss-link table
   uint32_t n_nodes;  // compact LDS layout: the link array starts 32 * n_nodes bytes after the box array
   uint32_t oct;
+  unsigned long long oct_x, oct_y, oct_z;   // wide walk: the lanes whose ray runs against x / y / z (ballots, set by traverse_round4)
   uint32_t node;     // next node to test, PT_END when the walk is over
   Best best;
   // STATS builds only: where the idle lane-slots of the box loop come from
@@ -160,6 +161,7 @@ PT_DEV void walk_init(Walk& w, f3 o, f3 d, uint32_t n_nodes, bool asm_scaled = f
   const float ts = asm_scaled ? PT_T_SCALE : 1.0f;
   w.inv = mk3(__builtin_amdgcn_rcpf(dx) * ts, __builtin_amdgcn_rcpf(dy) * ts, __builtin_amdgcn_rcpf(dz) * ts);
   w.noi = mk3(-(o.x * w.inv.x), -(o.y * w.inv.y), -(o.z * w.inv.z));
+  w.oct_x = w.oct_y = w.oct_z = 0ull;
   w.link_off = 8u + w.oct;
   w.n_nodes = n_nodes;
   w.node = n_nodes ? 0u : PT_END;
@@ -323,14 +325,14 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
 
 template <bool STATS>
 PT_DEV void walk_leaf(const float4* tris, Walk& w, uint32_t leaf_first, uint32_t leaf_count, uint32_t& n_tris,
-                      uint32_t& wave_tri_iters, bool small_det = false)
+                      uint32_t& wave_tri_iters, bool small_det = false, uint32_t stride = 3u /* float4 per triangle record */)
 {
   for (uint32_t k = 0; k < leaf_count; ++k) {
     if (STATS) {
       const unsigned long long act = __ballot(1);
       if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) ++wave_tri_iters;
     }
-    const uint32_t ti = (leaf_first + k) * 3;
+    const uint32_t ti = (leaf_first + k) * stride;
     mt_test<false>(tris[ti], tris[ti + 1], tris[ti + 2], w.o, w.d, w.best, small_det);
   }
   if (STATS) n_tris += leaf_count;
@@ -382,7 +384,12 @@ PT_DEV int texture_idx(const TexDesc& tex, float uvx, float uvy)
   return (y * tex.w + x) * tex.nb_chan;
 }
 
-struct Counters { uint32_t rays, nodes, tris, mesh_hits, nmap_hits, wave_node_iters, wave_tri_iters, fetch_events, fetch_rays, idle3[3]; };
+struct Counters { uint32_t rays, nodes, tris, mesh_hits, nmap_hits, wave_node_iters, wave_tri_iters, fetch_events, fetch_rays, idle3[3];
+                  // instrumented restart kernel: shader-clock cycles of a wave by phase — 0 pool refill, 1 box phases, 2 leaf phases, 3 light loop + shading,
+                  // 4 the whole round loop; 5 leaf phases entered (added by one lane per wave: sums over waves)
+                  unsigned long long cyc[10]; };   // [6] node fetch (issue -> data), [7] box tests + pushes, [8] pops after a visit without a hit (instrumented four-wide float walk)
+// one lane per executing wave adds a wave-level measurement
+#define PT_WAVE_ONE() ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1))
 
 // Result of the nearest-hit search of one intersect() call, before any shading data is touched:
 // 16 bytes, which is what travels through LDS when rays are compacted across a workgroup.
@@ -876,6 +883,11 @@ PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t sampl
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && s) atomicAdd(&p.stats[k], s);
   }
+  for (int k = 0; k < 10; ++k) {
+    unsigned long long s = cnt.cyc[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0 && s) atomicAdd(&p.stats[16 + k], s);
+  }
 }
 
 // COMPACT (the asm box loop's layout, see walk_to_leaf_lds): the 64-byte node is split into a 32-byte box record
@@ -1202,6 +1214,14 @@ struct Stack4 {
 #define PT_RS4_THREADS 1024     /* workgroup size of the wide-walk instantiation: ONE workgroup per CU, so one copy of the LDS treelet
                                    (256 / 512 / 1024 threads: atrium 1177 / 1233 / 1278, tessellated indoor 2868 / 2966 / 3081 Msamples/s) */
 #endif
+#ifndef PT_TREELET_SOA
+#define PT_TREELET_SOA 1        /* the LDS treelet chunk-major: 16-byte chunk q of node n at [q][n] instead of [n][q].  A wave's lanes read the
+                                   SAME chunk of DIFFERENT nodes: node-major, 128-byte (64-byte) nodes put them all on two (four) of the sixteen
+                                   4-bank groups — half of all LDS cycles of the atrium walk were bank conflicts (profiles/r04_base_*) —,
+                                   chunk-major they spread over all sixteen by node index */
+#endif
+#define PT_TREELET_STRIDE 512u  /* nodes per chunk plane of a 128-byte-node treelet (64-byte nodes: twice as many); the treelet's LDS region is
+                                   always 64 KB in this form, whatever the number of nodes staged */
 #ifndef PT_PUSH_BRANCHFREE
 #define PT_PUSH_BRANCHFREE 1    /* four-wide float walk: hit children pushed without branches when the LDS part of the stack has room */
 #endif
@@ -1249,17 +1269,217 @@ PT_DEV uint32_t stack4_pop(const Stack4& s, uint32_t& sp, float best_t)
   return PT_NONE;
 }
 
-// Visits interior node `cur`: tests its four child boxes, stacks the hit ones, returns the nearest (or pops).
+#ifndef PT_ASM_FETCH
+#define PT_ASM_FETCH 1          /* four-wide float walk: a node's eight 16-byte words fetched by fetch_node4 (below) instead of compiled loads */
+#endif
+// A visit's fetch: lanes whose node lies in the LDS treelet (cur < top_n; chunk-major, PT_TREELET_SOA) read it there, the others
+// read their node's line from L2 — BOTH KINDS IN FLIGHT TOGETHER.  Compiled, the two branches load into the same registers and the
+// compiler orders them: the global loads first, then `s_waitcnt vmcnt(..)` in front of every ds_read (it cannot know that the two
+// write disjoint lanes), so the treelet's LDS latency — bank conflicts included — came AFTER the memory latency in every box
+// iteration of the wave (profiles/r04_notes.md).  Loads only write the lanes EXEC enables, so no order is needed.
+typedef float pt_f4v __attribute__((ext_vector_type(4)));
+#define PT_TREELET_PLANE_BYTES_1 8192
+#define PT_TREELET_PLANE_BYTES_2 16384
+#define PT_TREELET_PLANE_BYTES_3 24576
+#define PT_TREELET_PLANE_BYTES_4 32768
+#define PT_TREELET_PLANE_BYTES_5 40960
+#define PT_TREELET_PLANE_BYTES_6 49152
+#define PT_TREELET_PLANE_BYTES_7 57344
+static_assert(PT_TREELET_STRIDE * 16u == PT_TREELET_PLANE_BYTES_1, "fetch_node4's plane offsets follow PT_TREELET_STRIDE");
+// `ahead`: the lane's top stack entry (entry sp - 1 of its LDS column), read with the node: a visit that hits nothing continues there.
+PT_DEV void fetch_node4(const float4* nodes4, const Stack4& stk, uint32_t cur, uint32_t sp, pt_f4v& r0, pt_f4v& r1, pt_f4v& r2, pt_f4v& r3, pt_f4v& r4,
+                        pt_f4v& r5, pt_f4v& r6, pt_f4v& r7, pt_u2v& ahead)
+{
+  static_assert(PT_TREELET_STRIDE * 16u * 7u < 65536u, "chunk plane offsets must fit a ds_read offset field");
+  const unsigned long long ga = (unsigned long long)(uintptr_t)nodes4 + ((unsigned long long)cur << 7);
+  const uint32_t la = (uint32_t)(uintptr_t)stk.top + (cur << 4);
+  const uint32_t pa = (uint32_t)(uintptr_t)stk.lds + ((sp - 1u) << 9);   // (sp == 0: an address below the column — whatever is there is never used)
+  unsigned long long save;
+  asm volatile(
+      "ds_read_b64 %[ah], %[pa]\n\t"
+      "v_cmp_le_u32 vcc, %[topn], %[cur]\n\t"
+      "s_and_saveexec_b64 %[save], vcc\n\t"                 // EXEC = lanes whose node is NOT in the treelet: the long latency first
+      "global_load_dwordx4 %[r0], %[ga], off\n\t"
+      "global_load_dwordx4 %[r1], %[ga], off offset:16\n\t"
+      "global_load_dwordx4 %[r2], %[ga], off offset:32\n\t"
+      "global_load_dwordx4 %[r3], %[ga], off offset:48\n\t"
+      "global_load_dwordx4 %[r4], %[ga], off offset:64\n\t"
+      "global_load_dwordx4 %[r5], %[ga], off offset:80\n\t"
+      "global_load_dwordx4 %[r6], %[ga], off offset:96\n\t"
+      "global_load_dwordx4 %[r7], %[ga], off offset:112\n\t"
+      "s_andn2_b64 exec, %[save], exec\n\t"                 // EXEC = the treelet's lanes of the visit
+      "ds_read_b128 %[r0], %[la]\n\t"
+      "ds_read_b128 %[r1], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_1) "\n\t"
+      "ds_read_b128 %[r2], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_2) "\n\t"
+      "ds_read_b128 %[r3], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_3) "\n\t"
+      "ds_read_b128 %[r4], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_4) "\n\t"
+      "ds_read_b128 %[r5], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_5) "\n\t"
+      "ds_read_b128 %[r6], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_6) "\n\t"
+      "ds_read_b128 %[r7], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_7) "\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+      : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5), [r6] "=&v"(r6), [r7] "=&v"(r7),
+        [ah] "=&v"(ahead), [save] "=&s"(save)
+      : [topn] "s"(stk.top_n), [cur] "v"(cur), [la] "v"(la), [ga] "v"(ga), [pa] "v"(pa)
+      : "vcc", "scc", "memory");
+}
+#ifndef PT_ASM_SELECT
+#define PT_ASM_SELECT 1         /* four-wide float walk: what follows the box tests of a visit — ranks, pushes, the nearest child or a pop — hand-scheduled */
+#endif
+// Second half of a visit of the four-wide float walk, hand-scheduled: from the four box-test results (m0..m3: the lanes whose
+// child c was hit; tn: entry distances; refs / ord: the node's references and order words) to the reference the lane processes
+// next.  Hit children that are not the nearest go on the lane's LDS stack at sp + rank (rank = hit children farther along the
+// ray, read off the node's order word for the ray's octant); every other child is written to the free slot sp + 3, so that the four
+// stores need no branch; the nearest hit child is returned; a visit without a hit pops — first the entry read ahead with the node
+// (`ahead`), then further ones through LDS — until an entry's distance does not lie beyond the best hit (PT_NONE: stack empty).
+// Same semantics as walk4_compute's tail (which remains the path of waves whose LDS stack part is nearly full); compiled, this
+// part of the visit was ~75 VALU and ~60 SALU instructions with a dozen branches, here 48 VALU, 14 SALU and one branch, and the
+// LDS round trip of a pop is off the critical path.  Scratch: v64..v77 (clobbered; wide kernels have a budget of 128 VGPRs).
+PT_DEV uint32_t walk4_select_asm(const Stack4& stk, const Walk& w, unsigned long long m0, unsigned long long m1, unsigned long long m2,
+                                 unsigned long long m3, float tn0, float tn1, float tn2, float tn3, pt_f4v refs, pt_f4v ord, pt_u2v ahead, uint32_t& sp)
+{
+  uint32_t cur;
+  unsigned long long save;
+  const uint32_t col = (uint32_t)(uintptr_t)stk.lds;
+  asm volatile(
+      "s_nop 1\n\t"                                          // m0..m3 were written by VALU compares
+      "v_cndmask_b32_e64 v64, 0, 1, %[m0]\n\t"
+      "v_cndmask_b32_e64 v65, 0, 2, %[m1]\n\t"
+      "v_cndmask_b32_e64 v66, 0, 4, %[m2]\n\t"
+      "v_cndmask_b32_e64 v67, 0, 8, %[m3]\n\t"
+      "v_or3_b32 v64, v64, v65, v66\n\t"
+      "v_or_b32 v64, v64, v67\n\t"                           // v64: hit bits
+      // the order word of the ray's octant: halfword `oct` of ord.xyzw (nibble c: the children visited AFTER child c)
+      "v_cndmask_b32_e64 v65, %[o0], %[o1], %[oy]\n\t"
+      "v_cndmask_b32_e64 v66, %[o2], %[o3], %[oy]\n\t"
+      "v_cndmask_b32_e64 v65, v65, v66, %[oz]\n\t"
+      "v_lshrrev_b32 v66, 16, v65\n\t"
+      "v_cndmask_b32_e64 v65, v65, v66, %[ox]\n\t"           // (bits above the halfword are masked off by the AND with the four hit bits)
+      "v_bcnt_u32_b32 v67, v64, 0\n\t"                       // v67: hit children
+      "v_add_u32 v68, -1, v67\n\t"                           // v68: the nearest one's rank (-1: none)
+      "v_and_b32 v69, v64, v65\n\t"
+      "v_bcnt_u32_b32 v69, v69, 0\n\t"                       // v69..v72: rank of child 0..3 = hit children farther than it
+      "v_lshrrev_b32 v70, 4, v65\n\t"
+      "v_and_b32 v70, v64, v70\n\t"
+      "v_bcnt_u32_b32 v70, v70, 0\n\t"
+      "v_lshrrev_b32 v71, 8, v65\n\t"
+      "v_and_b32 v71, v64, v71\n\t"
+      "v_bcnt_u32_b32 v71, v71, 0\n\t"
+      "v_lshrrev_b32 v72, 12, v65\n\t"
+      "v_and_b32 v72, v64, v72\n\t"
+      "v_bcnt_u32_b32 v72, v72, 0\n\t"
+      "v_lshl_add_u32 v73, %[sp], 9, %[col]\n\t"              // v73: LDS address of entry sp of this lane's column
+      "v_mov_b32 %[cur], -1\n\t"
+#define PT_SELECT_CHILD(RK, M, F, T)                                                                       \
+      "v_cmp_eq_u32 vcc, " RK ", v68\n\t"                                                                   \
+      "s_and_b64 vcc, vcc, " M "\n\t"                        /* the nearest hit child: visited next */       \
+      "v_cndmask_b32 %[cur], %[cur], " F ", vcc\n\t"                                                        \
+      "s_andn2_b64 vcc, " M ", vcc\n\t"                      /* hit, not the nearest: stacked at sp + rank */ \
+      "v_cndmask_b32 " RK ", 3, " RK ", vcc\n\t"                                                           \
+      "v_lshl_add_u32 " RK ", " RK ", 9, v73\n\t"                                                           \
+      "ds_write2_b32 " RK ", " F ", " T " offset1:1\n\t"
+      PT_SELECT_CHILD("v69", "%[m0]", "%[f0]", "%[t0]")
+      PT_SELECT_CHILD("v70", "%[m1]", "%[f1]", "%[t1]")
+      PT_SELECT_CHILD("v71", "%[m2]", "%[f2]", "%[t2]")
+      PT_SELECT_CHILD("v72", "%[m3]", "%[f3]", "%[t3]")
+#undef PT_SELECT_CHILD
+      "v_add_u32 %[sp], %[sp], v68\n\t"                       // sp += hit children - 1 (no hit: the entry below is the candidate)
+      // ---- lanes whose visit hit nothing pop
+      "v_cmp_eq_u32 vcc, 0, v67\n\t"
+      "s_and_saveexec_b64 %[save], vcc\n\t"
+      "s_cbranch_execz 3f\n\t"
+      "v_cmp_lt_i32 vcc, -1, %[sp]\n\t"                       // an entry is left (else the stack is empty: PT_NONE)
+      "s_and_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execz 2f\n\t"
+      "v_cmp_le_f32 vcc, %[a1], %[best]\n\t"                  // the entry read ahead: taken unless its distance lies beyond the best hit
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %[cur], %[cur], %[a0], vcc\n\t"
+      "s_andn2_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execz 2f\n\t"
+      "1:\n\t"
+      "v_add_u32 %[sp], -1, %[sp]\n\t"
+      "v_cmp_lt_i32 vcc, -1, %[sp]\n\t"
+      "s_and_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execz 2f\n\t"
+      "v_lshl_add_u32 v69, %[sp], 9, %[col]\n\t"
+      "ds_read_b64 v[76:77], v69\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_cmp_le_f32 vcc, v77, %[best]\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %[cur], %[cur], v76, vcc\n\t"
+      "s_andn2_b64 exec, exec, vcc\n\t"
+      "s_cbranch_execnz 1b\n\t"
+      "2:\n\t"
+      "3:\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "v_max_i32 %[sp], %[sp], 0\n\t"                         // (a lane that ran out of entries ended at -1)
+      : [cur] "=&v"(cur), [sp] "+v"(sp), [save] "=&s"(save)
+      : [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [ox] "s"(w.oct_x), [oy] "s"(w.oct_y), [oz] "s"(w.oct_z),
+        [t0] "v"(tn0), [t1] "v"(tn1), [t2] "v"(tn2), [t3] "v"(tn3), [f0] "v"(refs.x), [f1] "v"(refs.y), [f2] "v"(refs.z), [f3] "v"(refs.w),
+        [o0] "v"(ord.x), [o1] "v"(ord.y), [o2] "v"(ord.z), [o3] "v"(ord.w), [a0] "v"(ahead.x), [a1] "v"(ahead.y), [best] "v"(w.best.t), [col] "v"(col)
+      : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v76", "v77", "vcc", "scc", "memory");
+  return cur;
+}
+
+// The arithmetic of a visit on a fetched node: tests the four child boxes, stacks the hit ones, returns the nearest (or pops).
+PT_DEV uint32_t walk4_compute(float4 lx, float4 ly, float4 lz, float4 hx, float4 hy, float4 hz, uint4 refs, uint4 ord, const Stack4& stk, const Walk& w, uint32_t& sp);
+
+// Visits interior node `cur`: fetches it (LDS treelet or L2), then walk4_compute.
 template <bool STATS>
-PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk& w, uint32_t cur, uint32_t& sp)
+PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk& w, uint32_t cur, uint32_t& sp, Counters* cnt = nullptr)
 {
   float4 lx, ly, lz, hx, hy, hz;
   uint4 refs, ord;
+#if PT_ASM_FETCH && PT_TREELET_SOA
+  {
+    pt_f4v r0, r1, r2, r3, r4, r5, r6, r7;
+    long long tv0 = 0;
+    if (STATS) tv0 = clock64();
+    pt_u2v ahead;
+    fetch_node4(nodes4, stk, cur, sp, r0, r1, r2, r3, r4, r5, r6, r7, ahead);
+    if (STATS && cnt) { const long long tv1 = clock64(); if (PT_WAVE_ONE()) cnt->cyc[6] += (unsigned long long)(tv1 - tv0); }
+#if PT_ASM_SELECT
+    // Usual case, decided for the whole wave: four more entries fit into the LDS part of every lane's stack (then every entry a pop
+    // of this visit can reach is in LDS too)
+    if (__ballot(sp + 4u > stk.lds_entries) == 0ull) {
+      const float aix = __builtin_fabsf(w.inv.x), aiy = __builtin_fabsf(w.inv.y), aiz = __builtin_fabsf(w.inv.z);
+      float tn[4];
+      unsigned long long m[4];
+#define PT_CHILD(c, X)                                                                                                   \
+      {                                                                                                                  \
+        const float tcx = __builtin_fmaf(r0.X, w.inv.x, w.noi.x), tcy = __builtin_fmaf(r1.X, w.inv.y, w.noi.y),           \
+                    tcz = __builtin_fmaf(r2.X, w.inv.z, w.noi.z);                                                        \
+        const float n0x = __builtin_fmaf(-r3.X, aix, tcx), f0x = __builtin_fmaf(r3.X, aix, tcx);                          \
+        const float n0y = __builtin_fmaf(-r4.X, aiy, tcy), f0y = __builtin_fmaf(r4.X, aiy, tcy);                          \
+        const float n0z = __builtin_fmaf(-r5.X, aiz, tcz), f0z = __builtin_fmaf(r5.X, aiz, tcz);                          \
+        const float tnear = __builtin_fmaxf(__builtin_fmaxf(n0x, n0y), n0z);                                             \
+        const float tfar = __builtin_fminf(__builtin_fminf(f0x, f0y), f0z);                                              \
+        tn[c] = __builtin_fmaxf(tnear, 0.0f);                                                                            \
+        m[c] = __ballot(tn[c] <= __builtin_fminf(tfar, w.best.t));                                                       \
+      }
+      PT_CHILD(0, x) PT_CHILD(1, y) PT_CHILD(2, z) PT_CHILD(3, w)
+#undef PT_CHILD
+      return walk4_select_asm(stk, w, m[0], m[1], m[2], m[3], tn[0], tn[1], tn[2], tn[3], r6, r7, ahead, sp);
+    }
+#endif
+    lx = make_float4(r0.x, r0.y, r0.z, r0.w); ly = make_float4(r1.x, r1.y, r1.z, r1.w); lz = make_float4(r2.x, r2.y, r2.z, r2.w);
+    hx = make_float4(r3.x, r3.y, r3.z, r3.w); hy = make_float4(r4.x, r4.y, r4.z, r4.w); hz = make_float4(r5.x, r5.y, r5.z, r5.w);
+    refs = make_uint4(f_as_u(r6.x), f_as_u(r6.y), f_as_u(r6.z), f_as_u(r6.w));
+    ord = make_uint4(f_as_u(r7.x), f_as_u(r7.y), f_as_u(r7.z), f_as_u(r7.w));
+    return walk4_compute(lx, ly, lz, hx, hy, hz, refs, ord, stk, w, sp);
+  }
+#endif
   if (cur < stk.top_n) {
+#if PT_TREELET_SOA
+    constexpr uint32_t S = PT_TREELET_STRIDE;
+    const LdsCU4 q = treelet_lds(stk) + cur;
+#else
+    constexpr uint32_t S = 1u;
     const LdsCU4 q = treelet_lds(stk) + cur * 8u;
-    lx = lds_f4(q); ly = lds_f4(q + 1); lz = lds_f4(q + 2); hx = lds_f4(q + 3); hy = lds_f4(q + 4); hz = lds_f4(q + 5);
-    refs = lds_u4(q + 6);
-    ord = lds_u4(q + 7);
+#endif
+    lx = lds_f4(q); ly = lds_f4(q + S); lz = lds_f4(q + 2u * S); hx = lds_f4(q + 3u * S); hy = lds_f4(q + 4u * S); hz = lds_f4(q + 5u * S);
+    refs = lds_u4(q + 6u * S);
+    ord = lds_u4(q + 7u * S);
   } else {
     const float4* q = nodes4 + (size_t)cur * 8u;
     lx = q[0]; ly = q[1]; lz = q[2]; hx = q[3]; hy = q[4]; hz = q[5];
@@ -1268,6 +1488,11 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
   }
   // (references and order words are needed last, but fetched with the boxes: one round trip per visit)
   asm volatile("" : "+v"(refs.x), "+v"(refs.y), "+v"(refs.z), "+v"(refs.w), "+v"(ord.x), "+v"(ord.y), "+v"(ord.z), "+v"(ord.w));
+  return walk4_compute(lx, ly, lz, hx, hy, hz, refs, ord, stk, w, sp);
+}
+
+PT_DEV uint32_t walk4_compute(float4 lx, float4 ly, float4 lz, float4 hx, float4 hy, float4 hz, uint4 refs, uint4 ord, const Stack4& stk, const Walk& w, uint32_t& sp)
+{
   float tn[4];
   uint32_t hit = 0;
 #define PT_CHILD(c, X)                                                                                                   \
@@ -1362,8 +1587,14 @@ PT_DEV uint32_t walk8_visit(const float4* nodes8, const Stack4& stk, const Walk&
 {
   uint4 hd, ra, rb, pa, pb, pc;
   if (cur < stk.top_n) {
+#if PT_TREELET_SOA
+    constexpr uint32_t S = PT_TREELET_STRIDE;
+    const LdsCU4 q = treelet_lds(stk) + cur;
+#else
+    constexpr uint32_t S = 1u;
     const LdsCU4 q = treelet_lds(stk) + cur * 8u;
-    hd = lds_u4(q); ra = lds_u4(q + 1); rb = lds_u4(q + 2); pa = lds_u4(q + 3); pb = lds_u4(q + 4); pc = lds_u4(q + 5);
+#endif
+    hd = lds_u4(q); ra = lds_u4(q + S); rb = lds_u4(q + 2u * S); pa = lds_u4(q + 3u * S); pb = lds_u4(q + 4u * S); pc = lds_u4(q + 5u * S);
   } else {
     const uint4* q = reinterpret_cast<const uint4*>(nodes8) + (size_t)cur * 8u;
     hd = q[0]; ra = q[1]; rb = q[2]; pa = q[3]; pb = q[4]; pc = q[5];
@@ -1424,8 +1655,14 @@ PT_DEV uint32_t walk4q_visit(const float4* nodesq, const Stack4& stk, const Walk
 {
   uint4 hd, rf, pa, pb;
   if (cur < stk.top_n) {
+#if PT_TREELET_SOA
+    constexpr uint32_t S = 2u * PT_TREELET_STRIDE;
+    const LdsCU4 q = treelet_lds(stk) + cur;
+#else
+    constexpr uint32_t S = 1u;
     const LdsCU4 q = treelet_lds(stk) + cur * 4u;
-    hd = lds_u4(q); rf = lds_u4(q + 1); pa = lds_u4(q + 2); pb = lds_u4(q + 3);
+#endif
+    hd = lds_u4(q); rf = lds_u4(q + S); pa = lds_u4(q + 2u * S); pb = lds_u4(q + 3u * S);
   } else {
     const uint4* q = reinterpret_cast<const uint4*>(nodesq) + (size_t)cur * 4u;
     hd = q[0]; rf = q[1]; pa = q[2]; pb = q[3];
@@ -1485,6 +1722,7 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
   Walk w;
   walk_init(w, o, d, 1u);
   w.best = best;
+  w.oct_x = __ballot((w.oct & 1u) != 0u); w.oct_y = __ballot((w.oct & 2u) != 0u); w.oct_z = __ballot((w.oct & 4u) != 0u);
   Walk8 x8;
   x8.oct = 0u; x8.far = make_uint2(0u, 0u);
   if (MODE == 1) x8 = walk8_init(p, d);
@@ -1494,11 +1732,22 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
   if (t_eff > round_min) t_eff = round_min;
   if (t_eff < 1u) t_eff = 1u;
   for (;;) {
+    long long tb0 = 0;
+    if (STATS) tb0 = clock64();
     // box phase: every lane that holds an interior node visits it; the phase ends when fewer than walk_min lanes do
     for (;;) {
       const bool interior = cur < PT_LEAF_BIT;
       const uint32_t walkers = (uint32_t)__popcll(__ballot(interior));
       if (walkers == 0u) break;
+      if (STATS) {   // (every lane of the call is here) idle lane-slots of this box iteration, by cause
+        const uint32_t n_call = (uint32_t)__popcll(__ballot(1)), n_over = (uint32_t)__popcll(__ballot(cur == PT_NONE)),
+                       n_parked = (uint32_t)__popcll(__ballot(cur != PT_NONE && cur >= PT_LEAF_BIT));
+        if (PT_WAVE_ONE()) {
+          cnt.idle3[0] += 64u - n_call;   // no path in this call
+          cnt.idle3[1] += n_over;         // walk over, waiting for the round to end
+          cnt.idle3[2] += n_parked;       // parked at a leaf
+        }
+      }
       if (interior) {
         if (STATS) {
           cnt.nodes++;
@@ -1506,19 +1755,31 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
         }
         if (MODE == 1) cur = walk8_visit<STATS>(nodes4, stk, w, x8, cur, sp);
         else if (MODE == 2) cur = walk4q_visit<STATS>(nodes4, stk, w, x8.oct, cur, sp);
-        else cur = walk4_visit<STATS>(nodes4, stk, w, cur, sp);
+        else {
+          long long tv0 = 0;
+          if (STATS) tv0 = clock64();
+          cur = walk4_visit<STATS>(nodes4, stk, w, cur, sp, &cnt);
+          if (STATS) { const long long tv1 = clock64(); if (PT_WAVE_ONE()) cnt.cyc[7] += (unsigned long long)(tv1 - tv0); }   // (fetch included: [7] - [6] = arithmetic + pushes + pops)
+        }
       }
       if (walkers < walk_min) break;
+    }
+    long long tb1 = 0;
+    if (STATS) {
+      tb1 = clock64();
+      const bool any_leaf = __ballot(cur != PT_NONE && (cur & PT_LEAF_BIT)) != 0ull;
+      if (PT_WAVE_ONE()) { cnt.cyc[1] += (unsigned long long)(tb1 - tb0); if (any_leaf) cnt.cyc[5]++; }
     }
     // leaf phase: the leaf's triangle records come from L2 — fetch them all before the first test (one round trip
     // instead of one per triangle; leaves hold at most three, longer ones finish in the plain loop)
     if (cur != PT_NONE && (cur & PT_LEAF_BIT)) {
       const uint32_t first = cur & 0xFFFFFFu, count = (cur >> 24) & 0x7Fu;
-      const float4* t = tris + (size_t)first * 3u;
+      constexpr uint32_t TS = 3u;   // float4 per triangle record
+      const float4* t = tris + (size_t)first * TS;
       float4 r[9];
 #pragma unroll
       for (uint32_t k = 0; k < 3u; ++k)
-        if (k < count) { r[3 * k] = t[3 * k]; r[3 * k + 1] = t[3 * k + 1]; r[3 * k + 2] = t[3 * k + 2]; }
+        if (k < count) { r[3 * k] = t[TS * k]; r[3 * k + 1] = t[TS * k + 1]; r[3 * k + 2] = t[TS * k + 2]; }
 #pragma unroll
       for (uint32_t k = 0; k < 3u; ++k)
         if (k < count) {
@@ -1529,12 +1790,44 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
           mt_test<false>(r[3 * k], r[3 * k + 1], r[3 * k + 2], w.o, w.d, w.best, small_det);
         }
       if (STATS) cnt.tris += count < 3u ? count : 3u;
-      if (count > 3u) walk_leaf<STATS>(tris, w, first + 3u, count - 3u, cnt.tris, cnt.wave_tri_iters, small_det);
+      if (count > 3u) walk_leaf<STATS>(tris, w, first + 3u, count - 3u, cnt.tris, cnt.wave_tri_iters, small_det, TS);
       cur = stack4_pop(stk, sp, w.best.t);
     }
+    if (STATS && PT_WAVE_ONE()) cnt.cyc[2] += (unsigned long long)(clock64() - tb1);
     if ((uint32_t)__popcll(__ballot(cur != PT_NONE)) < t_eff) break;
   }
   best = w.best;
+}
+
+// XCD-local regions (restart kernel, KParams::xcd_regions): workgroups are dealt round-robin to the eight XCDs and every XCD has an L2
+// of its own (4 MB), so a scene walked from L2 wants each XCD to see a COMPACT part of the frame — primary rays and the first
+// bounces of neighbouring pixels touch the same nodes and triangles — instead of every eighth strip of it.  Ticket T belongs to
+// region T & 7 (a 4 x 2 grid of the launch's tile rectangle; heads hand out n_static + 8 t + h, so head h = XCD h serves region h
+// until it runs dry and then helps the next one); entry i = T >> 3 of a region is frame i % count of its tile i / count — the
+// frames of one tile run side by side on neighbouring waves and share their lines — and tiles are numbered in column strips eight
+// tiles wide.  Scheduling only: a path's arithmetic does not depend on when or where it runs.
+// Returns false when the region has no entry i (the ticket names no work).
+PT_DEV bool region_tile(const KParams& p, uint32_t ticket, uint32_t& col, uint32_t& row, uint32_t& k)
+{
+  const uint32_t r = ticket & 7u, i = ticket >> 3;
+  const uint32_t tiles_x = PT_KARG(p, tiles_x), tiles_y = PT_KARG(p, n_tiles) / tiles_x, count = PT_KARG(p, sample_count);
+  const uint32_t rx = r & 3u, ry = r >> 2;
+  const uint32_t x0 = rx * tiles_x / 4u, x1 = (rx + 1u) * tiles_x / 4u, y0 = ry * tiles_y / 2u, y1 = (ry + 1u) * tiles_y / 2u;
+  const uint32_t w = x1 - x0, h = y1 - y0;
+  const uint32_t j = i / count;
+  if (j >= w * h) return false;
+  k = i - j * count;
+  const uint32_t strips = w / 8u, full = strips * 8u * h;
+  if (j < full) {
+    const uint32_t s = j / (8u * h), rem = j - s * 8u * h;
+    row = y0 + rem / 8u;
+    col = x0 + s * 8u + (rem & 7u);
+  } else {
+    const uint32_t rem = j - full, wl = w - strips * 8u;
+    row = y0 + rem / wl;
+    col = x0 + strips * 8u + rem % wl;
+  }
+  return true;
 }
 
 // per-wave time stamps of a launch (ptamd_set_timeline): [4 gwave + slot] = device clock at 0 kernel entry, 1 scene staged,
@@ -1580,12 +1873,19 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
   stk.top = s_mem;
   stk.top_n = WIDE ? p.treelet_nodes : 0u;
   constexpr uint32_t NODE_F4 = VARIANT == PT_RS_WIDE4Q ? 4u : 8u;   // float4 per wide node
+  // float4s of the treelet's LDS region: chunk-major it is 64 KB whatever the number of nodes staged (plane stride fixed at compile time)
+  const uint32_t treelet_f4 = !WIDE ? 0u : (PT_TREELET_SOA ? (p.treelet_nodes ? 8u * PT_TREELET_STRIDE : 0u) : p.treelet_nodes * NODE_F4);
   if (WIDE) {
+#if PT_TREELET_SOA
+    constexpr uint32_t PLANE = PT_TREELET_STRIDE * (8u / NODE_F4);   // nodes per chunk plane
+    for (uint32_t i = threadIdx.x; i < p.treelet_nodes * NODE_F4; i += blockDim.x) s_mem[(i % NODE_F4) * PLANE + i / NODE_F4] = p.nodes4[i];
+#else
     stage_to_lds(s_mem, p.nodes4, p.treelet_nodes * NODE_F4);
+#endif
     __syncthreads();
   }
   PT_STAMP(1);
-  stk.lds = reinterpret_cast<uint2*>(s_mem + (size_t)p.treelet_nodes * NODE_F4) + (size_t)(threadIdx.x >> 6) * p.stack_lds_entries * 64u + lane;
+  stk.lds = reinterpret_cast<uint2*>(s_mem + (size_t)treelet_f4) + (size_t)(threadIdx.x >> 6) * p.stack_lds_entries * 64u + lane;
   stk.spill = p.stack_spill + (size_t)gwave * p.stack_spill_entries * 64u + lane;
   stk.lds_entries = p.stack_lds_entries;
   uint32_t cur = PT_NONE, sp = 0;   // wide walk: reference to process next, entries on the stack
@@ -1605,11 +1905,16 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
   uint32_t pool_rd = 64u, tile_x0 = 0, tile_y0 = 0, tile_k = 0;
   uint32_t tile_row_delta = 0;   // (frame row) - (row of the launch's buffers + row_begin): non-zero for interleaved bands
   uint32_t tile = 0, tile_end = 0;
-  uint32_t ticket = gwave;
+  // XCD-local regions (KParams::xcd_regions): the waves of XCD x take the tickets = x (mod 8), their first ones without an atomic
+  uint32_t ticket = PT_KARG(p, xcd_regions) ? ((blockIdx.x >> 3) * (THREADS / 64u) + (threadIdx.x >> 6)) * 8u + (blockIdx.x & 7u) : gwave;
+  ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);   // wave-uniform: the tile arithmetic stays scalar
+  uint32_t reg_col = 0, reg_row = 0, reg_k = 0;
   uint32_t head = blockIdx.x & 7u, dry = 0;
   bool have_ticket = true, exhausted = false;
   for (;;) {
     // ---- restart lanes without a path from the pool; an empty pool is refilled with a whole tile, all lanes active
+    long long tr0 = 0;
+    if (STATS) tr0 = clock64();
     unsigned long long need = __ballot(idle);
     while (need) {
       if (pool_rd >= 64u) {
@@ -1617,32 +1922,40 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
         if (tile >= tile_end) {
           const uint32_t tiles_per_ticket = PT_KARG(p, tiles_per_ticket);
           const uint32_t total = PT_KARG(p, n_tiles) * PT_KARG(p, sample_count); // (tile, frame) pairs
-          if (!have_ticket) {
-            uint32_t* heads = PT_KARG(p, tile_heads);
-            const uint32_t n_static = PT_KARG(p, n_static);
-            for (;;) {
+          // a ticket that names work: the wave's own first one (no atomic), then from this workgroup's XCD head; a head that has run
+          // dry sends the wave on to the next one for good
+          for (;;) {
+            if (!have_ticket) {
+              uint32_t* heads = PT_KARG(p, tile_heads);
               uint32_t t = 0;
               if (lane == 0) t = atomicAdd(heads + head * PT_HEAD_STRIDE, 1u);
               t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-              ticket = n_static + t * 8u + head;
-              if ((unsigned long long)ticket * tiles_per_ticket < total) break;
-              head = (head + 1u) & 7u;
-              if (++dry == 8u) break;
+              ticket = PT_KARG(p, n_static) + t * 8u + head;
             }
-            if (dry == 8u) { exhausted = true; PT_STAMP(2); break; }
+            have_ticket = false;
+            if (PT_KARG(p, xcd_regions) ? region_tile(p, ticket, reg_col, reg_row, reg_k) : ((unsigned long long)ticket * tiles_per_ticket < total)) break;
+            head = (head + 1u) & 7u;
+            if (++dry == 8u) break;
           }
-          have_ticket = false;
-          tile = ticket * tiles_per_ticket;
-          if (tile >= total) { exhausted = true; PT_STAMP(2); break; }
-          tile_end = tile + tiles_per_ticket;
-          if (tile_end > total) tile_end = total;
+          if (dry == 8u) { exhausted = true; PT_STAMP(2); break; }
+          if (PT_KARG(p, xcd_regions)) { tile = ticket; tile_end = ticket + 1u; }
+          else {
+            tile = ticket * tiles_per_ticket;
+            tile_end = tile + tiles_per_ticket;
+            if (tile_end > total) tile_end = total;
+          }
         }
         {
           const uint32_t n_tiles = PT_KARG(p, n_tiles), tiles_x = PT_KARG(p, tiles_x), row_begin = PT_KARG(p, row_begin);
-          tile_k = tile / n_tiles;
-          const uint32_t tl = tile - tile_k * n_tiles;
-          tile_x0 = (tl % tiles_x) * PT_TILE_W;
-          const uint32_t local_y0 = (tl / tiles_x) * PT_TILE_H;   // row inside this launch's share of the frame
+          uint32_t local_y0;                                      // row inside this launch's share of the frame
+          if (PT_KARG(p, xcd_regions)) {
+            tile_k = reg_k; tile_x0 = reg_col * PT_TILE_W; local_y0 = reg_row * PT_TILE_H;
+          } else {
+            tile_k = tile / n_tiles;
+            const uint32_t tl = tile - tile_k * n_tiles;
+            tile_x0 = (tl % tiles_x) * PT_TILE_W;
+            local_y0 = (tl / tiles_x) * PT_TILE_H;
+          }
           const uint32_t ilv_ranks = PT_KARG(p, ilv_ranks);
           if (ilv_ranks > 1u) {
             // interleaved bands: band j of ilv_rows rows belongs to rank j % ilv_ranks; this launch renders
@@ -1693,6 +2006,8 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
       need = __ballot(idle);
     }
     if (__ballot(!idle) == 0ull) break;
+    long long tr1 = 0;
+    if (STATS) { tr1 = clock64(); if (PT_WAVE_ONE()) cnt.cyc[0] += (unsigned long long)(tr1 - tr0); }
 
     if (!idle) {
       if (!walking) {
@@ -1733,6 +2048,10 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
           if (STATS) samples++;
         }
       }
+    }
+    if (STATS) {   // (outside the divergent part: every lane of the wave is here)
+      const long long tr3 = clock64();
+      if (PT_WAVE_ONE()) cnt.cyc[4] += (unsigned long long)(tr3 - tr0);   // (light loop + shading = the rest: [4] - [0] - [1] - [2])
     }
   }
   PT_STAMP(3);
@@ -2327,6 +2646,8 @@ static const void* restart_select(bool lds_resident, bool stats, const KParams* 
   return lds_resident ? restart_entry<true>(variant) : restart_entry<false>(variant);
 }
 
+// chunk-major treelet (PT_TREELET_SOA): bytes of its LDS region and the most 128-byte nodes it can hold (0: node-major, sized by the node count)
+uint32_t restart_treelet_region_bytes() { return PT_TREELET_SOA ? 8u * PT_TREELET_STRIDE * 16u : 0u; }
 uint32_t restart_threads(bool lds_resident) { return lds_resident ? PT_RS_THREADS : PT_RS4_THREADS; }
 // wide walk: resident workgroups per CU the launch bounds aim for (their LDS share holds the treelet and the waves' stacks)
 uint32_t restart_wide_blocks_per_cu() { return (PT_RS4_WAVES_PER_EU * 256u) / PT_RS4_THREADS; }

@@ -22,6 +22,7 @@ hipError_t split_blocks_per_cu(bool lds_resident, size_t scene_lds_bytes, int* o
 hipError_t launch_megakernel_split(const KParams& p, bool lds_resident, size_t scene_lds_bytes, bool stats,
                                    uint32_t n_blocks, hipStream_t stream);
 uint32_t restart_threads(bool lds_resident);
+uint32_t restart_treelet_region_bytes();   // != 0: the wide walk's LDS treelet is chunk-major in a region of this size (pt_kernels.hip: PT_TREELET_SOA)
 uint32_t restart_wide_blocks_per_cu();
 hipError_t restart_blocks_per_cu(bool lds_resident, size_t lds_bytes, int* out);
 hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t lds_bytes, bool stats,

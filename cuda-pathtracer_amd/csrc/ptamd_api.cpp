@@ -11,6 +11,7 @@
 #include "pt_device.h"
 #include "pt_launch.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -123,6 +124,7 @@ struct ptamd_context {
   uint32_t walk_min4 = 16;                // the same threshold for the four-wide walk (PTAMD_WALK_MIN4; 1/4/8/16/24: 813/902/960/994/971 Msamples/s)
   bool short_rcp = true;                  // restart kernel: 7-instruction exact 1/det where the scene allows it (PTAMD_SHORT_RCP=0: always the full division)
   uint32_t tiles_per_ticket = 1;
+  uint32_t xcd_regions = 0;               // restart kernel: XCD-local tile regions (0 never, 1 for scenes walked from L2, 2 always; PTAMD_XCD_REGIONS).  Off: measured -0.5 % on the atrium, -0.7 % on the headline (profiles/r04_notes.md)
 };
 
 namespace ptamd {
@@ -142,7 +144,7 @@ float frame_nb_inverse(float c)
 constexpr uint32_t kCompactMaxNodes = 896;   // 896 * 32 B = 28 KB of boxes below 0x8000 with 4 KB to spare for static LDS
 constexpr float kQuantisedMaxExtent = 1.0e8f;   // largest |coordinate| of a scene walked over quantised nodes (nodes4q / nodes8): see do_launch
 constexpr uint32_t kCompactMaxTris = 2047;   // a leaf's link code holds count << 11 | first triangle record in 15 bits (stage_scene)
-constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit); a 128-byte stride (one line per record) measured -0.7 % on the atrium
+constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit).  Round 4 re-measured on the atrium: a 128-byte stride (one line per record) -1.2 %, a 64-byte hot half + 64-byte cold half (one line, 17 MB instead of 30) level, -0.6 % on textured scenes (profiles/r04_notes.md)
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
 constexpr uint32_t kMaxLeaf = 2;   // 2 / 3 / 4 = 10902 / 10839 / 10160 Msamples/s on the headline now that a box test costs 16 VALU and a triangle test ~67 (scripts/gpu_r3_leaf2.sh: every bench configuration >= leaves of three)
 constexpr uint32_t kTicketRing = 1024;
@@ -175,6 +177,17 @@ int upload(T*& dst, const void* src, size_t bytes)
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&dst), bytes));
   if (src) PT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   else PT_HIP(hipMemset(dst, 0, bytes));
+  return PTAMD_OK;
+}
+
+// the same with `pad` zero bytes behind the table (reads that run past the last record stay inside the allocation)
+template <typename T>
+int upload_padded(T*& dst, const void* src, size_t bytes, size_t pad)
+{
+  dst = nullptr;
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&dst), bytes + pad));
+  PT_HIP(hipMemset(reinterpret_cast<char*>(dst) + bytes, 0, pad));
+  if (bytes) PT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return PTAMD_OK;
 }
 
@@ -450,15 +463,19 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       // ... and the waves' pools of fresh paths (PT_POOL_LDS_BYTES each), behind the stacks
       const uint32_t pools = ctx->pool_in_lds ? waves * PT_POOL_LDS_BYTES : 0u;
       // (the same LDS bytes hold twice as many 64-byte nodes)
-      const uint32_t treelet_want = ctx->treelet_nodes * (128u / node_bytes);
+      // chunk-major treelet (pt_kernels.hip: PT_TREELET_SOA): a region of fixed size whatever the number of nodes staged
+      const uint32_t region = restart_treelet_region_bytes();
+      uint32_t treelet_want = ctx->treelet_nodes * (128u / node_bytes);
+      if (region && treelet_want > region / node_bytes) treelet_want = region / node_bytes;
       uint32_t treelet = treelet_want < p.n_nodes4 ? treelet_want : p.n_nodes4;
-      if (treelet * node_bytes + waves * 512u * 4u + pools > share) treelet = (share - pools - waves * 512u * 4u) / node_bytes;   // keep >= 4 stack entries
-      uint32_t fit = (share - pools - treelet * node_bytes) / (waves * 512u);
+      if (!region && treelet * node_bytes + waves * 512u * 4u + pools > share) treelet = (share - pools - waves * 512u * 4u) / node_bytes;   // keep >= 4 stack entries
+      const uint32_t treelet_bytes = region ? (treelet ? region : 0u) : treelet * node_bytes;
+      uint32_t fit = (share - pools - treelet_bytes) / (waves * 512u);
       if (const char* ev = tuning_env("PTAMD_STACK_LDS")) { int v = std::atoi(ev); if (v >= 1 && (uint32_t)v <= fit) fit = (uint32_t)v; }   // tuning knob
       p.treelet_nodes = treelet;
       p.stack_lds_entries = need < fit ? need : fit;
       p.stack_spill_entries = need - p.stack_lds_entries;
-      launch_lds = (size_t)treelet * node_bytes + (size_t)p.stack_lds_entries * waves * 512u;
+      launch_lds = (size_t)treelet_bytes + (size_t)p.stack_lds_entries * waves * 512u;
       if (pools) {
         p.pool_lds_offset = (uint32_t)launch_lds;
         if (!p.pool_lds_offset) p.pool_lds_offset = 16u;
@@ -502,6 +519,13 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
     const uint32_t n_tickets = (p.n_tiles * count + tiles_per_ticket - 1u) / tiles_per_ticket;
     const uint32_t useful = (n_tickets + waves_per_block - 1u) / waves_per_block;
     if (n_blocks > useful) n_blocks = useful;
+    // XCD-local regions (pt_kernels.hip: region_tile): the ticket -> tile map that keeps every XCD on a compact part of the frame.
+    // Needs whole groups of eight workgroups (one per XCD) and one tile per ticket.
+    if (restart && tiles_per_ticket == 1u && n_blocks >= 8u && (uint64_t)p.n_tiles * count < (1ull << 28) &&
+        (ctx->xcd_regions == 2u || (ctx->xcd_regions == 1u && !resident))) {
+      n_blocks &= ~7u;
+      p.xcd_regions = 1u;
+    }
     // seeds of frames frame_nb+1.. are hashed on the device; the tonemap uses the last frame number
     if (count > 1) p.frame_nb_f = (float)(int)(l->frame_nb + count - 1u);
     p.frame_nb_inv = frame_nb_inverse(p.frame_nb_f);
@@ -640,8 +664,8 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   std::unique_ptr<ptamd_context> ctx(new (std::nothrow) ptamd_context());
   if (!ctx) { set_error("ptamd_create: out of memory"); return PTAMD_ERR_ARG; }
   ctx->device = device_ordinal;
-  PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), 16 * sizeof(unsigned long long)));
-  PT_HIP(hipMemset(ctx->d_stats, 0, 16 * sizeof(unsigned long long)));
+  PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), 32 * sizeof(unsigned long long)));   // 0..12 counters, 14 self-test, 15 error flag, 16..21 phase cycles
+  PT_HIP(hipMemset(ctx->d_stats, 0, 32 * sizeof(unsigned long long)));
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), kTicketRing * sizeof(uint32_t)));
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_heads), (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
   PT_HIP(hipMemset(ctx->d_heads, 0, (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
@@ -699,6 +723,10 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   if (const char* e = tuning_env("PTAMD_ROUND_DIV")) { // tuning knob
     int v = std::atoi(e);
     ctx->round_div = (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+  }
+  if (const char* e = tuning_env("PTAMD_XCD_REGIONS")) { // tuning knob
+    int v = std::atoi(e);
+    ctx->xcd_regions = (uint32_t)(v < 0 ? 0 : (v > 2 ? 2 : v));
   }
   if (const char* e = tuning_env("PTAMD_TILES_PER_TICKET")) {
     int v = std::atoi(e);
@@ -830,7 +858,7 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
       (rc = upload(d.nodes4, bvh.nodes4.data(), bvh.nodes4.size() * 4)) ||
       (rc = upload(d.nodes8, bvh.nodes8.data(), bvh.nodes8.size() * 4)) ||
       (rc = upload(d.nodes4q, bvh.nodes4q.data(), bvh.nodes4q.size() * 4)) ||
-      (rc = upload(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4)) ||
+      (rc = upload_padded(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4, 128)) ||   // (the merged wide walk reads eight 16-byte words from a leaf's first record)
       (rc = upload(d.tris_brute, brute.data(), brute.size() * 4)) ||
       (rc = upload(d.shade, shade.data(), shade.size() * 4)) ||
       (rc = upload(d.materials, mats.data(), mats.size() * 4)) ||
@@ -916,6 +944,7 @@ int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_t
   PT_HIP(hipSetDevice(ctx->device));
   hipStream_t st = launch ? static_cast<hipStream_t>(launch->stream) : nullptr;
   PT_HIP(hipMemsetAsync(ctx->d_stats, 0, 13 * sizeof(unsigned long long), st));
+  PT_HIP(hipMemsetAsync(ctx->d_stats + 16, 0, 10 * sizeof(unsigned long long), st));
   int rc = do_launch(ctx, launch, true);
   if (rc != PTAMD_OK) return rc;
   PT_HIP(hipStreamSynchronize(st));
@@ -926,6 +955,15 @@ int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_t
   out->wave_node_iters = h[6]; out->wave_tri_iters = h[7];
   out->fetch_events = h[8]; out->fetch_rays = h[9];
   out->idle_unstarted = h[10]; out->idle_finished = h[11]; out->idle_parked = h[12];
+  return PTAMD_OK;
+}
+
+int ptamd_phase_cycles(ptamd_context* ctx, uint64_t out[10])
+{
+  if (!ctx || !out) { set_error("ptamd_phase_cycles: null argument"); return PTAMD_ERR_ARG; }
+  PT_HIP(hipSetDevice(ctx->device));
+  PT_HIP(hipDeviceSynchronize());
+  PT_HIP(hipMemcpy(out, ctx->d_stats + 16, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return PTAMD_OK;
 }
 

@@ -138,6 +138,7 @@ SIGNATURES = {
     "ptamd_set_timeline": (C.c_int, [C.c_void_p, C.c_uint32]),
     "ptamd_read_timeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]),
     "ptamd_device_error_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "ptamd_phase_cycles": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ptamd_gamma_table_selftest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ptamd_trace_rays": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
                                    C.POINTER(C.c_int32)]),

@@ -145,6 +145,14 @@ class Context:
         N.check(self._lib.ptamd_raytrace_stats(self._h, C.byref(launch), C.byref(st)))
         return {n: getattr(st, n) for n, _ in N.TraceStats._fields_}
 
+    def phase_cycles(self) -> dict:
+        """Shader-clock cycles by phase, summed over the waves of the last raytrace_stats launch of the restart kernel."""
+        v = (C.c_uint64 * 10)()
+        N.check(self._lib.ptamd_phase_cycles(self._h, v))
+        d = dict(zip(("refill", "box_phases", "leaf_phases", "lights_and_shading", "round_loop", "leaf_phases_entered", "node_fetches", "visits", "_8", "_9"), [int(x) for x in v]))
+        d["lights_and_shading"] = d["round_loop"] - d["refill"] - d["box_phases"] - d["leaf_phases"]   # (what the three stamps leave)
+        return d
+
     def trace_rays(self, scene_id: int, rays: np.ndarray, kernel: int = N.KERNEL_BVH) -> np.ndarray:
         """rays float32[n,6] = dir.xyz, origin.xyz -> int32[n,4] = kind, index, t bits, 0."""
         rays = np.ascontiguousarray(rays, dtype=np.float32)

@@ -305,6 +305,12 @@ typedef struct {
  * returns exact traversal counts (synchronous; outputs are written as usual). */
 int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_trace_stats* out);
 
+/* Where the waves of the last ptamd_raytrace_stats launch of PTAMD_KERNEL_BVH_RESTART spent their shader-clock cycles, summed
+ * over the waves (instrumented build only): out[0] pool refill (tickets, path_begin), [1] box phases of the wide walk, [2] its
+ * leaf phases, [3] unused (light loop + shading = [4] - [0] - [1] - [2]), [4] the whole round loop, [5] leaf phases entered, [6] node fetches of the four-wide walk (issue to data), [7] its visits as a whole
+ * (fetch, box tests, pushes, pops), [8], [9] unused.  Synchronises. */
+int ptamd_phase_cycles(ptamd_context* ctx, uint64_t out[10]);
+
 /* Where a launch's time goes (measurement hook of the default kernel; profiles/r03_tail_*).  After ptamd_set_timeline(ctx, n)
  * every launch of PTAMD_KERNEL_BVH_RESTART with at most n waves in its grid records four device time stamps per wave
  * (hipDeviceAttributeWallClockRate ticks): kernel entry, scene staged, the moment the wave found no tile ticket left, exit.

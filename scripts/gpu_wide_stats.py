@@ -29,6 +29,7 @@ with tempfile.TemporaryDirectory(prefix="ptamd_atrium_") as d:
         l = ctx.make_launch(fr.surface, fr.accum, sid, cid, hs.camera_struct(), W, H, frame_nb=1, bounces=B,
                             kernel=P.KERNEL_BVH_RESTART, frame_count=SPP)
         s = ctx.raytrace_stats(l)
+        cyc = ctx.phase_cycles()
         rays, samples = max(s["rays"], 1), max(s["samples"], 1)
         out = {k: v for k, v in s.items() if v}
         out.update({
@@ -40,6 +41,18 @@ with tempfile.TemporaryDirectory(prefix="ptamd_atrium_") as d:
             "wave_tri_iterations_per_sample": s["wave_tri_iters"] / samples,
             "rounds_per_64_samples": s["fetch_events"] * 64.0 / samples,
             "walks_completed_per_round": s["fetch_rays"] / max(s["fetch_events"], 1),
+            "box_iteration_lane_slots": {"active": s["nodes_visited"] / (64.0 * max(s["wave_node_iters"], 1)),
+                                         "no_path_in_this_round": s["idle_unstarted"] / (64.0 * max(s["wave_node_iters"], 1)),
+                                         "walk_over_waiting_for_round_end": s["idle_finished"] / (64.0 * max(s["wave_node_iters"], 1)),
+                                         "parked_at_a_leaf": s["idle_parked"] / (64.0 * max(s["wave_node_iters"], 1))},
+            "max_leaf_size": ctx.scene_info(sid)["max_leaf_size"],
+            "phase_cycles_summed_over_waves": cyc,
+            "phase_share_of_round_loop": {k: v / max(cyc["round_loop"], 1) for k, v in cyc.items() if k in ("refill", "box_phases", "leaf_phases", "lights_and_shading")},
+            "cycles_per_box_iteration": cyc["box_phases"] / max(s["wave_node_iters"], 1),
+            "cycles_per_node_fetch_issue_to_data": cyc["node_fetches"] / max(s["wave_node_iters"], 1),
+            "cycles_per_visit_fetch_tests_pushes_pops": cyc["visits"] / max(s["wave_node_iters"], 1),
+            "cycles_per_leaf_phase": cyc["leaf_phases"] / max(cyc["leaf_phases_entered"], 1),
+            "cycles_per_round_of_shading": cyc["lights_and_shading"] / max(s["fetch_events"], 1),
             "build_id": P.native.load().ptamd_build_id().decode(),
         })
         print(json.dumps(out))
