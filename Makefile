@@ -9,7 +9,7 @@ ARCH     ?= gfx950
 HIPFLAGS := $(EXTRA_HIPFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -Iinclude -I$(PKG)/host -I$(PKG)/csrc \
             -Wall -Wextra -Wno-unused-parameter
 LIB      := $(PKG)/libptamd.so
-SRCS     := $(PKG)/csrc/pt_kernels.hip $(PKG)/csrc/ptamd_api.cpp $(PKG)/host/scene_loader.cpp $(PKG)/host/bvh_builder.cpp $(PKG)/host/image_decode.cpp $(PKG)/host/image_png.cpp $(PKG)/host/image_resize.cpp
+SRCS     := $(PKG)/csrc/pt_kernels.hip $(PKG)/csrc/pt_kernels_fma.hip $(PKG)/csrc/ptamd_api.cpp $(PKG)/host/scene_loader.cpp $(PKG)/host/bvh_builder.cpp $(PKG)/host/image_decode.cpp $(PKG)/host/image_png.cpp $(PKG)/host/image_resize.cpp
 HDRS     := include/ptamd.h $(PKG)/host/ptamd_internal.h $(PKG)/csrc/pt_device.h $(PKG)/csrc/pt_launch.h
 # identity of the build: EVERY source and header the library is compiled from + the flags, in this order (the host half decides what
 # the device executes too: leaf size, launch geometry and slab sizing in ptamd_api.cpp, the tree's shape in bvh_builder.cpp).

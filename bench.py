@@ -75,7 +75,8 @@ def parse_args(argv=None):
                     help="load the scene with the MTL's backslash texture paths normalised (indoor.scene then gets its real textures)")
     ap.add_argument("--tessellate", type=int, default=1, help="split every face into n*n (24 -> ~257k tris: round 1's configs[3] stand-in)")
     ap.add_argument("--aperture", type=float, default=None, help="override the camera aperture (configs[4]: 0.113)")
-    ap.add_argument("--kernel", choices=["restart", "persistent", "split", "bvh", "blockwise", "brute"], default="restart")
+    ap.add_argument("--kernel", choices=["restart", "restart_fma", "persistent", "split", "bvh", "blockwise", "brute"], default="restart",
+                    help="restart_fma: the opt-in contracted instantiation (NOT bit-exact: include/ptamd.h PTAMD_KERNEL_BVH_RESTART_FMA)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames rendered concurrently on separate HIP streams, each with its own buffers (double "
                          "buffering, as the reference double-buffers its GL renderbuffers: driver/interop.cpp:107-111).  "
@@ -210,7 +211,7 @@ def cpu_baseline(hs, cube, width, height, bounces, target_seconds):
                       f"{cores} threads, {dt:.1f} s"}
 
 
-KERNEL_SYMBOL = {"persistent": "pt_megakernel_persistent", "restart": "pt_megakernel_restart", "blockwise": "pt_megakernel_blockwise",
+KERNEL_SYMBOL = {"persistent": "pt_megakernel_persistent", "restart": "pt_megakernel_restart", "restart_fma": "ptamd_fma::pt_megakernel_restart", "blockwise": "pt_megakernel_blockwise",
                  "split": "pt_megakernel_split", "bvh": "pt_megakernel", "brute": "pt_megakernel"}
 
 
@@ -224,8 +225,9 @@ class Workload:
         self.W, self.H, self.spp, self.B = W, H, spp, B
         self.world, self.rank = world, rank
         self.kernel = {"auto": P.KERNEL_AUTO, "bvh": P.KERNEL_BVH, "brute": P.KERNEL_BRUTE_FORCE, "persistent": P.KERNEL_BVH_PERSISTENT,
-                       "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT, "restart": P.KERNEL_BVH_RESTART}[kernel_name]
-        self.batched = batched and kernel_name in ("auto", "persistent", "split", "restart") and spp > 1
+                       "blockwise": P.KERNEL_BVH_BLOCKWISE, "split": P.KERNEL_BVH_SPLIT, "restart": P.KERNEL_BVH_RESTART,
+                       "restart_fma": P.KERNEL_BVH_RESTART_FMA}[kernel_name]
+        self.batched = batched and kernel_name in ("auto", "persistent", "split", "restart", "restart_fma") and spp > 1
         self.n_slots = n_slots
         self.hs = hs
         self.dev = torch.device("cuda", local_rank)
@@ -330,7 +332,8 @@ class Workload:
         per_launch = self.frames_per_launch
         for k in range(1, self.spp + 1, per_launch):
             l = self.ctx.make_launch(scratch.surface, scratch.accum, self.sid, self.cid, self.hs.camera_struct(), self.W,
-                                     self.H, frame_nb=k, bounces=self.B, rows=scratch.rows, kernel=self.kernel,
+                                     self.H, frame_nb=k, bounces=self.B, rows=scratch.rows,
+                                     kernel=P.KERNEL_BVH_RESTART if self.kernel == P.KERNEL_BVH_RESTART_FMA else self.kernel,   # (the contracted kernel has no instrumented build)
                                      band_local_buffers=True, interleave=self.interleave, frame_count=per_launch)
             s = self.ctx.raytrace_stats(l)
             for key in stats:
@@ -347,17 +350,64 @@ class Workload:
 
 
 def load_pmc(path, kernel_name, W, H, spp, B, frames_per_launch, tessellate, scene, build_id):
-    """profiles/pmc_latest.json applies only to the workload it was collected on."""
+    """A PMC record (scripts/summarize_pmc.py) applies only to the workload it was collected on, and only to the build whose id it
+    carries: counters of another build are marked stale and not used (frac / achieved / traffic stay null)."""
     try:
         with open(path) as f:
             pj = json.load(f)
     except (OSError, ValueError):
         return None
-    pj["stale"] = pj.get("build_id") != build_id   # counters of another build of the device code: not used for the roofline
+    pj["stale"] = pj.get("build_id") != build_id
     ok = (pj.get("kernel") == kernel_name and pj.get("workload") == f"{W}x{H}" and pj.get("spp") == spp
           and pj.get("bounces") == B and pj.get("frames_per_launch") == frames_per_launch and tessellate == 1
           and pj.get("scene", "indoor.scene") == scene)
     return pj if ok else None
+
+
+def roofline_block(pmc, kernel_symbol, kern_ms, n_slots, samples_per_launch, compulsory_launch, build_id, with_traffic=True):
+    """The VALU-issue roofline of one workload: achieved = VALU wave-instructions per launch (PMC record of this workload and this
+    build) x concurrent launches / the live HIP-event duration of a launch; beside it what the counters say about the memory side
+    (bytes read beyond L2 against the compulsory bytes, requests beyond L1, share of wave cycles spent waiting)."""
+    stale = bool(pmc is not None and pmc.get("stale"))
+    if stale:
+        pmc = None
+    g = (lambda k: None) if pmc is None else pmc.get
+    valu_per_sample, active_lanes = g("valu_insts_per_sample"), g("active_lanes")
+    traffic = g("hbm_bytes_per_launch") if with_traffic else None
+    valu_launch = None if valu_per_sample is None else valu_per_sample * samples_per_launch
+    achieved = None if valu_launch is None else valu_launch * n_slots / (kern_ms * 1e-3) / 1e9
+    frac = None if achieved is None else achieved / VALU_PEAK_GINST
+    per_s = n_slots / (kern_ms * 1e-3) / 1e9
+    return {
+        "bound": "valu_issue", "achieved": None if achieved is None else round(achieved, 2),
+        "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s", "frac": None if frac is None else round(frac, 4),
+        "traffic": traffic,
+        "kernel": kernel_symbol, "kernel_ms_per_launch": round(kern_ms, 4), "concurrent_launches": n_slots,
+        "samples_per_launch": int(samples_per_launch),
+        "valu_insts_per_launch": None if valu_launch is None else int(valu_launch),
+        "valu_insts_per_sample": valu_per_sample,
+        "active_lanes": active_lanes,   # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: lanes (of 64) per issued VALU instruction
+        "useful_lane_frac": None if (frac is None or active_lanes is None) else round(frac * active_lanes / 64.0, 4),
+        # the same instructions against the clocks the profiled dispatch actually ran for: share of the VALU issue slots of the
+        # launch's 1/concurrent_launches of the GPU
+        "valu_busy_at_measured_clock": None if (pmc is None or not g("gui_active_cycles_per_launch") or not g("valu_insts_per_launch"))
+        else round(g("valu_insts_per_launch") * VALU_CYCLES * n_slots / (N_SIMDS * g("gui_active_cycles_per_launch")), 4),
+        "pmc_source": g("source"), "build_id": build_id, "pmc_stale": stale,
+        "peak_note": f"{N_SIMDS} SIMDs x {CLOCK_GHZ} GHz / {VALU_CYCLES} cycles per wave64 VALU instruction "
+                     "(MI355X_MICROARCH.md: v_fma_f32 2 cyc on SIMD-32; 64 lanes x 2 flop x this = the 157.3 TFLOP/s FP32 vector peak)",
+        "hbm_peak_gbps": HBM_PEAK_GBPS,
+        "compulsory_hbm_bytes_per_launch": int(compulsory_launch),
+        "compulsory_hbm_gbps": round(compulsory_launch * per_s, 2),
+        "hbm_gbps_measured": None if traffic is None else round(traffic * per_s, 2),
+        "hbm_frac_measured": None if traffic is None else round(traffic * per_s / HBM_PEAK_GBPS, 4),
+        "refetch_factor": None if (traffic is None or not compulsory_launch) else round(traffic / compulsory_launch, 2),
+        # walks served from the caches: requests beyond L1 per sample, their mean latency, L2 hit rate, share of wave cycles waiting
+        "l1_to_l2_requests_per_sample": None if g("l1_to_l2_requests_per_launch") is None else round(g("l1_to_l2_requests_per_launch") / samples_per_launch, 2),
+        "l1_to_l2_mean_latency_cycles": None if g("l1_to_l2_mean_latency_cycles") is None else round(g("l1_to_l2_mean_latency_cycles"), 1),
+        "l2_hit_rate": None if (g("l2_hits_per_launch") is None or g("l2_misses_per_launch") is None)
+        else round(g("l2_hits_per_launch") / max(g("l2_hits_per_launch") + g("l2_misses_per_launch"), 1.0), 4),
+        "wait_any_share_of_wave_cycles": None if g("wait_any_share_of_wave_cycles") is None else round(g("wait_any_share_of_wave_cycles"), 4),
+    }
 
 
 def main():
@@ -468,6 +518,15 @@ def main():
             qdt, q_ms = seq.run(k2, 2, 0.0, sync_each=True)
             seq.close()
             extra["value_sequential_host_sync"] = round(W * H * spp * k2 / qdt / 1e6, 3)
+        # (b') the opt-in contracted instantiation on the same workload: NOT bit-exact (held to BASELINE.md section 5's tolerance by the
+        # GPU suite), reported beside `value`, never as it
+        if args.kernel == "restart":
+            fw = Workload(P, torch, dist, hs, cube, W, H, spp, B, "restart_fma", n_slots, args.share, not args.sequential, local_rank)
+            fdt, f_ms = fw.run(args.steps, args.warmup, args.settle_ms)
+            fw.close()
+            extra["value_fma"] = round(W * H * spp * args.steps / fdt / 1e6, 3)
+            extra["value_fma_note"] = ("PTAMD_KERNEL_BVH_RESTART_FMA: the same kernel with floating-point contraction allowed (what the reference's nvcc "
+                                       "build permits); not bit-exact — all but <= 1e-4 of the pixels identical, mean image within 2e-6 (BASELINE.md section 5)")
         # (c) the other single-GPU configurations of BASELINE.json, a few steps each
         if is_headline and args.kernel == "restart":
             others = []
@@ -477,16 +536,16 @@ def main():
             def load_crate_land():
                 return P.HostScene.load(os.path.join(ROOT, "assets", "crate_land.scene"))
 
-            for name, loader, (w2, h2, s2, b2), ap, k in (
+            for name, loader, (w2, h2, s2, b2), ap, k, pmc_file, pmc_scene in (
                     ("configs[3]: atrium.obj (generated Sponza-class OBJ, 264 832 triangles, through the loader; walked from L2) "
-                     "1920x1080 4 spp 4 bounces", lambda: P.HostScene.load(atrium_scene()), (1920, 1080, 4, 4), None, 6),
+                     "1920x1080 4 spp 4 bounces", lambda: P.HostScene.load(atrium_scene()), (1920, 1080, 4, 4), None, 6, "pmc_atrium.json", "atrium.scene"),
                     ("configs[4]: indoor.scene 3840x2160 16 spp 8 bounces aperture 0.113",
-                     lambda: P.HostScene.load(args.scene), (3840, 2160, 16, 8), 0.113, 3),
+                     lambda: P.HostScene.load(args.scene), (3840, 2160, 16, 8), 0.113, 3, "pmc_c4k.json", "indoor.scene aperture 0.113"),
                     # the texture path (sampleTexture + normal maps, intersection.cuh:20-65,216-242): dependent 16 B / 12 B gathers
                     ("textured indoor.scene: the maps indoor.mtl names (backslash paths normalised; 1024^2 parquet / concrete albedo + normal "
-                     "maps, wooden_planck, crack2: 66 MB of float texels) 1920x1080 4 spp 4 bounces", load_textured_indoor, (1920, 1080, 4, 4), None, 8),
+                     "maps, wooden_planck, crack2: 66 MB of float texels) 1920x1080 4 spp 4 bounces", load_textured_indoor, (1920, 1080, 4, 4), None, 8, "pmc_textured_indoor.json", "indoor.scene (textured)"),
                     ("crate_land.scene: 1024^2 RGBA + normal maps, bilinear 1024^2 cubemap (field_with_house.jpg), aperture 0.113, "
-                     "1920x1080 4 spp 4 bounces", load_crate_land, (1920, 1080, 4, 4), None, 8)):
+                     "1920x1080 4 spp 4 bounces", load_crate_land, (1920, 1080, 4, 4), None, 8, "pmc_crate_land.json", "crate_land.scene")):
                 sc = loader()
                 if ap is not None:
                     sc.camera["aperture"] = ap
@@ -494,57 +553,29 @@ def main():
                 odt, o_ms = o.run(k, 1, args.settle_ms)
                 oi = o.info
                 o.close()
+                # the counters of THIS workload on THIS build (scripts/gpu_round4.sh collects one record per bench configuration);
+                # a record of another build prices nothing: pmc_stale
+                bid = P.native.load().ptamd_build_id().decode()
+                opmc = load_pmc(os.path.join(os.path.dirname(args.pmc_json), pmc_file), "restart", w2, h2, s2, b2, s2, 1, pmc_scene, bid)
                 others.append({"workload": name, "value": round(w2 * h2 * s2 * k / odt / 1e6, 3), "unit": "Msamples/s",
                                "steps": k, "ms_per_step": round(odt / k * 1e3, 4), "kernel_ms_per_launch": round(o_ms, 4),
-                               "frames_in_flight": 2, "faces": oi["n_faces"], "bvh_nodes": oi["n_nodes"]})
+                               "frames_in_flight": 2, "faces": oi["n_faces"], "bvh_nodes": oi["n_nodes"],
+                               "roofline": roofline_block(opmc, KERNEL_SYMBOL["restart"], o_ms, 2, w2 * h2 * s2, 28 * w2 * h2 * s2 + sc.scene_bytes(), bid)})
             extra["other_configs"] = others
 
     if rank == 0:
         build_id = P.native.load().ptamd_build_id().decode()
-        pmc = load_pmc(args.pmc_json, args.kernel, W, H, spp, B, frames_per_launch, args.tessellate, os.path.basename(args.scene), build_id)
-        pmc_stale = bool(pmc is not None and pmc.get("stale"))
-        if pmc_stale:
-            pmc = None   # frac / achieved / traffic stay null: the committed counters belong to another build of the kernels
-        valu_per_sample = active_lanes = traffic = None
-        if pmc is not None:
-            valu_per_sample = pmc.get("valu_insts_per_sample")
-            active_lanes = pmc.get("active_lanes")
-            if world == 1:
-                traffic = pmc.get("hbm_bytes_per_launch")
-        valu_launch = None if valu_per_sample is None else valu_per_sample * samples_per_launch
-        # chip-wide issue rate while the timed region runs: n_slots launches side by side, each lasting kern_ms
-        achieved = None if valu_launch is None else valu_launch * n_slots / (kern_ms * 1e-3) / 1e9
-        frac = None if achieved is None else achieved / VALU_PEAK_GINST
+        scene_tag = "atrium.scene" if args.atrium else os.path.basename(args.scene) + (" (textured)" if args.fix_backslashes else "")
+        pmc = load_pmc(args.pmc_json, args.kernel, W, H, spp, B, frames_per_launch, args.tessellate, scene_tag, build_id)
         box_iters = stats["wave_node_iters"]
-        roof = {
-            "bound": "valu_issue", "achieved": None if achieved is None else round(achieved, 2),
-            "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s", "frac": None if frac is None else round(frac, 4),
-            "traffic": traffic,
-            "kernel": KERNEL_SYMBOL[args.kernel], "kernel_ms_per_launch": round(kern_ms, 4), "concurrent_launches": n_slots,
-            "samples_per_launch": int(samples_per_launch),
-            "valu_insts_per_launch": None if valu_launch is None else int(valu_launch),
-            "valu_insts_per_sample": valu_per_sample,
-            "active_lanes": active_lanes,   # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: lanes (of 64) per issued VALU instruction
-            "useful_lane_frac": None if (frac is None or active_lanes is None) else round(frac * active_lanes / 64.0, 4),
-            # the same instructions against the clocks the profiled dispatch actually ran for (the chip holds ~1.8 GHz, not
-            # 2.4, under this load): share of the VALU issue slots of the launch's 1/concurrent_launches of the GPU
-            "valu_busy_at_measured_clock": None if (pmc is None or not pmc.get("gui_active_cycles_per_launch") or not pmc.get("valu_insts_per_launch"))
-            else round(pmc["valu_insts_per_launch"] * VALU_CYCLES * n_slots / (N_SIMDS * pmc["gui_active_cycles_per_launch"]), 4),
-            "pmc_source": None if pmc is None else pmc.get("source"),
-            "build_id": build_id, "pmc_stale": pmc_stale,
-            "peak_note": f"{N_SIMDS} SIMDs x {CLOCK_GHZ} GHz / {VALU_CYCLES} cycles per wave64 VALU instruction "
-                         "(MI355X_MICROARCH.md: v_fma_f32 2 cyc on SIMD-32; 64 lanes x 2 flop x this = the 157.3 TFLOP/s FP32 vector peak)",
-            "hbm_peak_gbps": HBM_PEAK_GBPS,
-            "compulsory_hbm_bytes_per_launch": int(compulsory_launch),
-            "compulsory_hbm_gbps": round(compulsory_launch * n_slots / (kern_ms * 1e-3) / 1e9, 2),
-            "hbm_gbps_measured": None if traffic is None else round(traffic * n_slots / (kern_ms * 1e-3) / 1e9, 2),
-            "hbm_frac_measured": None if traffic is None else round(traffic * n_slots / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        roof = roofline_block(pmc, KERNEL_SYMBOL[args.kernel], kern_ms, n_slots, samples_per_launch, compulsory_launch, build_id, with_traffic=world == 1)
+        roof.update({
             "nodes_per_ray": round(stats["nodes_visited"] / max(stats["rays"], 1), 2),
             "tris_per_ray": round(stats["tris_tested"] / max(stats["rays"], 1), 2),
             "rays_per_sample": round(stats["rays"] / max(stats["samples"], 1), 3),
             # instrumented build of the same kernel: share of the box-test loop's lane slots that test a box
             "box_loop_lane_utilisation": None if box_iters == 0 else round(stats["nodes_visited"] / (64.0 * box_iters), 4),
-        }
+        })
         # SURVEY §8(d)'s per-unit figure, re-homed: the traversal's algorithmic bytes are LDS reads on this scene (36 B per node
         # visit: 32-byte box + 4-byte link word; 48 B per triangle record), counted exactly by the instrumented build, plus the
         # 28 B of accumulator / surface traffic per sample; against the aggregate LDS read rate (MI355X_MICROARCH.md: ~150 TB/s for

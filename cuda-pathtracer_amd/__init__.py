@@ -6,7 +6,7 @@ this package is the thin host mirror of the reference interface.  The directory 
 carries a hyphen; import it as `cuda_pathtracer_amd` (alias module at the repo root).
 """
 from . import native
-from .native import (KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, KERNEL_BVH_PERSISTENT, KERNEL_BVH_BLOCKWISE, KERNEL_BVH_SPLIT, KERNEL_BVH_RESTART,
+from .native import (KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, KERNEL_BVH_PERSISTENT, KERNEL_BVH_BLOCKWISE, KERNEL_BVH_SPLIT, KERNEL_BVH_RESTART, KERNEL_BVH_RESTART_FMA,
                      PtamdError)
 from .scene import (HostScene, cubemap_for_scene, cubemap_from_color, cubemap_from_cross,
                     FACE_DTYPE, MATERIAL_DTYPE, LIGHT_DTYPE, TEXTURE_DTYPE, CAMERA_DTYPE)

@@ -2555,6 +2555,7 @@ __global__ void __launch_bounds__(256) pt_trace_rays_kernel(PT_KERNEL_PARAMS, co
 
 // ---------------------------------------------------------------- launchers
 
+#ifndef PT_FMA_BUILD   /* (the contracted instantiation, pt_kernels_fma.hip, only carries the restart kernel) */
 template <int KIND, bool LDS_RES, bool STATS>
 static hipError_t launch_variant(const KParams& p, dim3 grid, size_t lds_bytes, hipStream_t stream)
 {
@@ -2626,10 +2627,22 @@ hipError_t launch_megakernel_persistent(const KParams& p, bool lds_resident, siz
   return hipLaunchKernel(fn, dim3(n_blocks), dim3(PT_PERSISTENT_THREADS), args, lds_bytes, stream);
 }
 
+#endif
+
 template <bool LDS_RES>
 static const void* restart_entry(int variant)
 {
   switch (variant) {
+#ifdef PT_FMA_BUILD
+    case PT_RS_BRUTE: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_BRUTE>);
+    default: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_PLAIN>);
+  }
+}
+template <bool LDS_RES>
+static const void* restart_entry_unused(int variant)
+{
+  switch (variant) {
+#endif
     case PT_RS_STATS: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_STATS>);
     case PT_RS_STAMPS: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_STAMPS>);
     case PT_RS_BRUTE: return reinterpret_cast<const void*>(pt_megakernel_restart<LDS_RES, PT_RS_BRUTE>);
@@ -2677,6 +2690,7 @@ hipError_t launch_megakernel_restart(const KParams& p, bool lds_resident, size_t
   return hipLaunchKernel(fn, dim3(n_blocks), dim3(restart_threads(lds_resident)), args, lds_bytes, stream);
 }
 
+#ifndef PT_FMA_BUILD
 static const void* split_select(bool lds_resident, bool stats)
 {
   if (lds_resident)
@@ -2834,4 +2848,17 @@ hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, 
   return hipGetLastError();
 }
 
+#else
+} // namespace (ptamd_fma in this translation unit)
+// C entry points of the contracted instantiation (pt_kernels_fma.hip): ptamd_api.cpp calls these for PTAMD_KERNEL_BVH_RESTART_FMA
+extern "C" hipError_t ptamd_fma_restart_blocks_per_cu(int lds_resident, size_t lds_bytes, int* out)
+{
+  return ptamd::restart_blocks_per_cu(lds_resident != 0, lds_bytes, out);
+}
+extern "C" hipError_t ptamd_fma_launch_restart(const void* kparams, int lds_resident, size_t lds_bytes, uint32_t n_blocks, hipStream_t stream)
+{
+  return ptamd::launch_megakernel_restart(*reinterpret_cast<const ptamd::KParams*>(kparams), lds_resident != 0, lds_bytes, false, n_blocks, stream);
+}
+namespace ptamd {
+#endif
 } // namespace ptamd

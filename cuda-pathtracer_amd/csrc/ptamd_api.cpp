@@ -81,7 +81,7 @@ struct ptamd_context {
   int n_cus = 0;
   // resident workgroups per CU of the persistent kernels: depends on the scene's dynamic LDS bytes, so the cache is
   // keyed by them ([0] persistent, [1] blockwise, [2] split, [3] restart)
-  struct Occupancy { size_t lds = ~(size_t)0; int blocks_per_cu = -1; } occupancy[4];
+  struct Occupancy { size_t lds = ~(size_t)0; int blocks_per_cu = -1; } occupancy[5];   // ([4]: the contracted restart kernel)
   // parked samples of batched launches, one scratch per stream: launches on one stream are ordered, launches on
   // different streams of one context (frames in flight, ptamd_launch.machine_share) must not share a buffer
   // Four slabs per stream.  [0..2] are used in turn by pipelined launches (megakernel on an internal stream, below): the
@@ -252,12 +252,12 @@ int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
   if (l->bounces == 0 || l->bounces > 1024) { set_error("ptamd_raytrace: bounces out of range (1..1024)"); return PTAMD_ERR_ARG; }
   if (l->frame_count > 4096) { set_error("ptamd_raytrace: frame_count out of range (<= 4096)"); return PTAMD_ERR_ARG; }
   if (l->frame_count > 1 && l->moved) { set_error("ptamd_raytrace: batched frames must be static (moved = 0)"); return PTAMD_ERR_ARG; }
-  if (l->kernel > PTAMD_KERNEL_BVH_RESTART) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
+  if (l->kernel > PTAMD_KERNEL_BVH_RESTART_FMA) { set_error("ptamd_raytrace: unknown kernel kind"); return PTAMD_ERR_ARG; }
   if (l->machine_share > 64) { set_error("ptamd_raytrace: machine_share out of range (<= 64)"); return PTAMD_ERR_ARG; }
   if (l->interleave_ranks > 1) {
     if (l->interleave_rank >= l->interleave_ranks || l->interleave_rows == 0 || l->interleave_rows % 8u != 0 || l->interleave_rows > 4096 ||
         !l->band_local_buffers || l->row_begin != 0 || l->row_end != l->height || l->moved ||
-        (l->kernel != PTAMD_KERNEL_AUTO && l->kernel != PTAMD_KERNEL_BVH_RESTART)) {
+        (l->kernel != PTAMD_KERNEL_AUTO && l->kernel != PTAMD_KERNEL_BVH_RESTART && l->kernel != PTAMD_KERNEL_BVH_RESTART_FMA)) {
       set_error("ptamd_raytrace: interleaved bands need rank < ranks, rows a multiple of 8, band-local buffers, the whole frame as row range, "
                 "a static frame and the default kernel");
       return PTAMD_ERR_ARG;
@@ -266,10 +266,22 @@ int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
   return PTAMD_OK;
 }
 
-int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
+// the contracted instantiation of the restart kernel (pt_kernels_fma.hip)
+extern "C" hipError_t ptamd_fma_restart_blocks_per_cu(int lds_resident, size_t lds_bytes, int* out);
+extern "C" hipError_t ptamd_fma_launch_restart(const void* kparams, int lds_resident, size_t lds_bytes, uint32_t n_blocks, hipStream_t stream);
+
+int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats)
 {
-  int rc = validate_launch(ctx, l);
+  int rc = validate_launch(ctx, l_in);
   if (rc != PTAMD_OK) return rc;
+  // PTAMD_KERNEL_BVH_RESTART_FMA: everything below treats the launch as one of the restart kernel; only the code object differs
+  const bool fma = l_in->kernel == PTAMD_KERNEL_BVH_RESTART_FMA;
+  ptamd_launch l_copy;
+  const ptamd_launch* l = l_in;
+  if (fma) {
+    if (stats) { set_error("ptamd_raytrace_stats: the contracted kernel has no instrumented build"); return PTAMD_ERR_ARG; }
+    l_copy = *l_in; l_copy.kernel = PTAMD_KERNEL_BVH_RESTART; l = &l_copy;
+  }
   PT_HIP(hipSetDevice(ctx->device));
   const DeviceScene& s = ctx->scenes[l->scene_id];
   const DeviceCubemap& cm = ctx->cubemaps[l->cubemap_id];
@@ -450,9 +462,9 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       // for 1 / 0 (axis-parallel rays) the inner fma stays finite for coordinates up to kQuantisedMaxExtent; beyond it the float
       // nodes are walked, whose planes overflow one by one (an infinite slab distance is still a correct one)
       const bool quantised_ok = s.extent <= kQuantisedMaxExtent;
-      const bool wide8 = ctx->wide8 && quantised_ok && !stats && !p.brute_walk && !ctx->d_timeline && s.n_nodes8 != 0;
+      const bool wide8 = ctx->wide8 && quantised_ok && !stats && !fma && !p.brute_walk && !ctx->d_timeline && s.n_nodes8 != 0;
       if (wide8) { p.nodes4 = s.nodes8; p.n_nodes4 = s.n_nodes8; p.wide8 = 1u; }
-      const bool wide4q = !wide8 && ctx->wide4q && quantised_ok && !stats && !p.brute_walk && !ctx->d_timeline && s.nodes4q != nullptr;
+      const bool wide4q = !wide8 && ctx->wide4q && quantised_ok && !stats && !fma && !p.brute_walk && !ctx->d_timeline && s.nodes4q != nullptr;
       if (wide4q) { p.nodes4 = s.nodes4q; p.wide8 = 2u; }
       const uint32_t node_bytes = wide4q ? 64u : 128u;
       const uint32_t need = (wide8 ? 7u * s.depth8 : 3u * s.depth4) + 1u;   // a visit stacks all hit children but the nearest
@@ -494,12 +506,12 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
         launch_lds = p.pool_lds_offset + (size_t)waves * PT_POOL_LDS_BYTES;
       }
     }
-    ptamd_context::Occupancy& occ = ctx->occupancy[split ? 2 : (restart ? 3 : 0)];
+    ptamd_context::Occupancy& occ = ctx->occupancy[split ? 2 : (restart ? (fma ? 4 : 3) : 0)];
     const size_t occ_key = resident ? (restart ? launch_lds : lds) : (restart ? launch_lds + 1u : 0);
     if (occ.blocks_per_cu < 0 || occ.lds != occ_key) {
       int q = -1;
       e = split ? split_blocks_per_cu(resident, lds, &q)
-                : (restart ? restart_blocks_per_cu(resident, launch_lds, &q) : persistent_blocks_per_cu(resident, lds, &q));
+                : (restart ? (fma ? ptamd_fma_restart_blocks_per_cu(resident ? 1 : 0, launch_lds, &q) : restart_blocks_per_cu(resident, launch_lds, &q)) : persistent_blocks_per_cu(resident, lds, &q));
       if (e != hipSuccess || q < 1) { occ.blocks_per_cu = -1; return hip_fail("occupancy query of the persistent kernel", e); }
       occ.blocks_per_cu = q; occ.lds = occ_key;
     }
@@ -587,9 +599,9 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l, bool stats)
       if (!ctx->heads_clean[slot]) PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_heads), 0, 8u * PT_HEAD_STRIDE, mega_stream));
       ctx->heads_clean[slot] = false;
     }
-    if (restart && ctx->d_timeline && n_blocks * waves_per_block <= ctx->timeline_waves) p.timeline = ctx->d_timeline;
+    if (restart && !fma && ctx->d_timeline && n_blocks * waves_per_block <= ctx->timeline_waves) p.timeline = ctx->d_timeline;
     if (split) { p.tiles_per_ticket = 1; e = launch_megakernel_split(p, resident, lds, stats, n_blocks, stream); }
-    else if (restart) e = launch_megakernel_restart(p, resident, launch_lds, stats, n_blocks, mega_stream);
+    else if (restart) e = fma ? ptamd_fma_launch_restart(&p, resident ? 1 : 0, launch_lds, n_blocks, mega_stream) : launch_megakernel_restart(p, resident, launch_lds, stats, n_blocks, mega_stream);
     else e = launch_megakernel_persistent(p, resident, lds, stats, n_blocks, stream);
     if (e == hipSuccess && overlap) {
       PT_HIP(hipEventRecord(sc->mega_done[scratch_slab], mega_stream));

@@ -24,6 +24,7 @@ class PtamdError(RuntimeError):
 
 PTAMD_OK, PTAMD_ERR_ARG, PTAMD_ERR_HIP, PTAMD_ERR_IO, PTAMD_ERR_LIMIT = 0, 1, 2, 3, 4
 KERNEL_AUTO, KERNEL_BRUTE_FORCE, KERNEL_BVH, KERNEL_BVH_PERSISTENT, KERNEL_BVH_BLOCKWISE, KERNEL_BVH_SPLIT, KERNEL_BVH_RESTART = 0, 1, 2, 3, 4, 5, 6
+KERNEL_BVH_RESTART_FMA = 7   # opt-in, NOT bit-exact: the restart kernel with floating-point contraction allowed (include/ptamd.h)
 
 
 class Float3(C.Structure):

@@ -19,6 +19,7 @@ ap.add_argument("--atrium", action="store_true")
 ap.add_argument("--scene", default="indoor.scene")
 ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--fix-backslashes", action="store_true")
+ap.add_argument("--aperture", type=float, default=None)
 bargs, _ = ap.parse_known_args(sys.argv[4:])
 
 acc = {}
@@ -75,7 +76,7 @@ fetch_kb, write_kb = res.get("FETCH_SIZE"), res.get("WRITE_SIZE")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 os.environ.setdefault("PTAMD_NO_TORCH_PRELOAD", "1")
 from cuda_pathtracer_amd import native as _native   # the id of the library the passes ran with (same work tree)
-rec = {"build_id": _native.load().ptamd_build_id().decode(), "kernel": kernel, "scene": "atrium.scene" if bargs.atrium else os.path.basename(bargs.scene) + (" (textured)" if bargs.fix_backslashes else ""), "workload": f"{bargs.width}x{bargs.height}", "spp": bargs.spp, "bounces": bargs.bounces,
+rec = {"build_id": _native.load().ptamd_build_id().decode(), "kernel": kernel, "scene": "atrium.scene" if bargs.atrium else os.path.basename(bargs.scene) + (" (textured)" if bargs.fix_backslashes else "") + (f" aperture {bargs.aperture:g}" if bargs.aperture is not None else ""), "workload": f"{bargs.width}x{bargs.height}", "spp": bargs.spp, "bounces": bargs.bounces,
        "frames_per_launch": fpl, "samples_per_launch": samples,
        "valu_insts_per_launch": res.get("SQ_INSTS_VALU"), "valu_insts_per_sample": d.get("valu_insts_per_sample"),
        "active_lanes": d.get("valu_active_lanes_per_inst(of 64)"),

@@ -972,3 +972,54 @@ def test_error_behaviour(P, gpu_ctx, indoor):
     # empty row band is a no-op
     gpu_ctx.raytrace_ex(launch(rows=(7, 7)))
     torch.cuda.synchronize()
+
+
+def test_contracted_kernel_stays_inside_the_stated_tolerance(P, gpu_ctx, indoor):
+    """PTAMD_KERNEL_BVH_RESTART_FMA — the opt-in instantiation with floating-point contraction allowed, what the reference's own
+    nvcc build permits (cuda_opengl/CMakeLists.txt:20-22) — is NOT bit-exact and is not meant to be.  It is held to the measured
+    drift between faithful builds of the integrator (tests/test_tolerance_study.py): on the headline scene a
+    pixel is a function of the sequence of surfaces its path hits, so all but <= 1e-4 of the pixels must be IDENTICAL to the exact
+    kernel's and the mean image must agree to 2e-6; on a scene whose radiance is continuous in the hit point (crate_land) >= 99 % of
+    the pixels must lie within 1e-4 and >= 99.85 % within +-1 LSB, the mean image within 1e-5.  Batched and single-frame launches of
+    the contracted kernel must agree with each other bit for bit (it is deterministic; only its rounding differs)."""
+    import torch
+    from test_tolerance_study import (INDOOR_MAX_MEAN_IMAGE_DELTA, INDOOR_MAX_SHARE_BEYOND_1E4, INDOOR_MAX_SHARE_BEYOND_1LSB,
+                                      TEXTURED_MAX_MEAN_IMAGE_DELTA, TEXTURED_MAX_SHARE_BEYOND_1E4, TEXTURED_MAX_SHARE_BEYOND_1LSB)
+    needs_batched_default()
+
+    def both(hs, cube, W, H, spp, bounces):
+        sid, cid = gpu_ctx.upload_scene(hs), gpu_ctx.upload_cubemap(cube)
+        out = []
+        for kernel in (P.KERNEL_BVH_RESTART, P.KERNEL_BVH_RESTART_FMA):
+            fr = P.FrameRenderer(gpu_ctx, sid, cid, hs.camera_struct(), W, H)
+            fr.render(spp=spp, bounces=bounces, kernel=kernel, batched=True)
+            torch.cuda.synchronize()
+            out.append((fr.accum.cpu().numpy().astype(np.float64) / spp, fr.surface.cpu().numpy()))
+        # the contracted kernel once more, one launch per frame: must equal its own batched launch bit for bit
+        fr = P.FrameRenderer(gpu_ctx, sid, cid, hs.camera_struct(), W, H)
+        fr.render(spp=spp, bounces=bounces, kernel=P.KERNEL_BVH_RESTART_FMA, batched=False)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(fr.surface.cpu().numpy(), out[1][1])
+        np.testing.assert_array_equal((fr.accum.cpu().numpy().astype(np.float64) / spp), out[1][0])
+        return out
+
+    def drift(exact, fma):
+        d = np.nan_to_num(np.abs(fma[0] - exact[0]), nan=1.0).max(axis=2)
+        lsb = np.abs(fma[1][..., :3].astype(np.int32) - exact[1][..., :3].astype(np.int32)).max(axis=2)
+        mean_delta = np.abs(fma[0].mean(axis=(0, 1)) - exact[0].mean(axis=(0, 1))).max()
+        return float((d > 1e-4).mean()), float((lsb > 1).mean()), float(mean_delta), float((d == 0).mean())
+
+    e, f = both(indoor, P.cubemap_for_scene(indoor), 1920, 1080, 4, 4)
+    beyond, lsb, mean_delta, identical = drift(e, f)
+    assert beyond <= INDOOR_MAX_SHARE_BEYOND_1E4 and lsb <= INDOOR_MAX_SHARE_BEYOND_1LSB and mean_delta <= INDOOR_MAX_MEAN_IMAGE_DELTA, \
+        (beyond, lsb, mean_delta)
+    assert identical >= 1.0 - INDOOR_MAX_SHARE_BEYOND_1E4, identical
+    assert identical < 1.0, "the contracted kernel rendered the exact kernel's image: is it the contracted code object?"
+
+    hs2 = P.HostScene.load(os.path.join(ASSETS, "crate_land.scene"))
+    cube2 = P.cubemap_for_scene(hs2, asset_folder=ASSETS)
+    e, f = both(hs2, cube2, 480, 270, 4, 4)
+    beyond, lsb, mean_delta, identical = drift(e, f)
+    assert beyond <= TEXTURED_MAX_SHARE_BEYOND_1E4 and lsb <= TEXTURED_MAX_SHARE_BEYOND_1LSB and mean_delta <= TEXTURED_MAX_MEAN_IMAGE_DELTA, \
+        (beyond, lsb, mean_delta)
+    assert identical < 1.0
