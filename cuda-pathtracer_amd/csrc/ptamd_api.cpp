@@ -78,6 +78,7 @@ struct ptamd_context {
   uint32_t* d_heads = nullptr;   // kTicketRing sets of 8 ticket heads, PT_HEAD_STRIDE dwords apart (persistent kernel)
   uint32_t ticket_next = 0;
   std::vector<bool> heads_clean;   // per ring slot: its ticket heads are known to be zero (creation, or its last user's resolve pass)
+  std::vector<bool> slot_pinned;   // per ring slot: baked into a captured graph (skipped by the rotation until ptamd_release_captured)
   int n_cus = 0;
   // resident workgroups per CU of the persistent kernels: depends on the scene's dynamic LDS bytes, so the cache is
   // keyed by them ([0] persistent, [1] blockwise, [2] split, [3] restart)
@@ -99,6 +100,11 @@ struct ptamd_context {
     bool resolved_valid[3] = { false, false, false };
     hipEvent_t last_done = nullptr;                   // recorded behind every launch of this stream: is the host running ahead?
     uint32_t flip = 0;
+    bool no_pipeline = false;     // the three pipelining slabs could not be allocated once: this stream's launches stay on the caller's stream
+    // Graph capture (ptamd.h "What a captured launch pins"): a launch captured on this stream baked slab [3] and its ring slots of
+    // ticket heads into a graph.  Until ptamd_release_captured the slab is not reallocated and the slots are not handed to anyone else.
+    bool captured = false;
+    std::vector<uint32_t> pinned_slots;
   };
   std::vector<SampleScratch> sample_scratch;
   // Consecutive launches on ONE caller stream overlap: the megakernel of a launch (which reads scene tables and writes only
@@ -149,6 +155,7 @@ constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conser
 constexpr uint32_t kMaxLeaf = 2;   // 2 / 3 / 4 = 10902 / 10839 / 10160 Msamples/s on the headline now that a box test costs 16 VALU and a triangle test ~67 (scripts/gpu_r3_leaf2.sh: every bench configuration >= leaves of three)
 constexpr uint32_t kTicketRing = 1024;
 constexpr size_t kMaxScratchStreams = 16;   // sample scratches kept per context (one per stream that batches frames)
+constexpr uint32_t kMaxFramesPerSlab = 4;   // a batched launch parks at most this many frames at a time: longer batches are issued as consecutive launches of <= 4 frames (the same bits by the contract of frame_count), so a stream's slab bytes do not depend on frame_count
 #ifndef PT_PERSISTENT_THREADS
 #define PT_PERSISTENT_THREADS 512
 #endif
@@ -270,7 +277,9 @@ int validate_launch(const ptamd_context* ctx, const ptamd_launch* l)
 extern "C" hipError_t ptamd_fma_restart_blocks_per_cu(int lds_resident, size_t lds_bytes, int* out);
 extern "C" hipError_t ptamd_fma_launch_restart(const void* kparams, int lds_resident, size_t lds_bytes, uint32_t n_blocks, hipStream_t stream);
 
-int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats)
+// later_chunk: the launch is the second or a later part of a batch the library cut into parts (kMaxFramesPerSlab): it follows
+// its predecessor on the same stream by construction, so it is pipelined behind it whatever the caller's machine_share
+int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats, bool later_chunk = false)
 {
   int rc = validate_launch(ctx, l_in);
   if (rc != PTAMD_OK) return rc;
@@ -281,6 +290,20 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats)
   if (fma) {
     if (stats) { set_error("ptamd_raytrace_stats: the contracted kernel has no instrumented build"); return PTAMD_ERR_ARG; }
     l_copy = *l_in; l_copy.kernel = PTAMD_KERNEL_BVH_RESTART; l = &l_copy;
+  }
+  // Batches longer than kMaxFramesPerSlab: consecutive launches of at most that many frames.  frame_count = N is by contract the
+  // same accumulator and final surface as N consecutive calls, so this changes no bit; what it bounds is the sample slab
+  // (rows x width x 12 bytes x 4 frames whatever N: 0.4 GB at 4K instead of 1.6 GB at 16 spp, and four slabs per stream).
+  if (l_in->frame_count > kMaxFramesPerSlab) {
+    for (uint32_t k0 = 0; k0 < l_in->frame_count; k0 += kMaxFramesPerSlab) {
+      ptamd_launch part = *l_in;
+      part.frame_nb = l_in->frame_nb + k0;
+      part.frame_count = l_in->frame_count - k0 < kMaxFramesPerSlab ? l_in->frame_count - k0 : kMaxFramesPerSlab;
+      if (k0 > 0) part.reset_accumulation = 0;
+      rc = do_launch(ctx, &part, stats, k0 > 0);
+      if (rc != PTAMD_OK) return rc;
+    }
+    return PTAMD_OK;
   }
   PT_HIP(hipSetDevice(ctx->device));
   const DeviceScene& s = ctx->scenes[l->scene_id];
@@ -331,14 +354,16 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats)
   p.error_flag = ctx->d_stats + 15;
 
   uint32_t which = l->kernel == PTAMD_KERNEL_AUTO ? ctx->default_kernel : l->kernel;
-  // Box margins cover the slab test's rounding, (|origin| + |plane|) * 2^-22, for origins inside the scene's extent
+  // Box margins cover the slab test's rounding, at most 1.75 (|origin| + |plane|) * 2^-22, for origins inside the scene's extent
   // (bvh_builder.cpp).  A camera so far outside it that this bound exceeds the margin (e.g. 1e5 units from a
   // unit-sized scene) would need wider boxes: such launches test every face instead — the reference algorithm, exact
   // for any origin — inside the restart kernel (KParams::brute_walk: all its launch shapes keep working, interleaved
   // bands and batched frames included) or, for the other kernels, through the exhaustive tile kernel.
   const float cam_far = std::fmax(std::fabs(cam.position.x), std::fmax(std::fabs(cam.position.y), std::fabs(cam.position.z))) +
                         std::fabs(cam.aperture);
-  const bool far_origin = !((cam_far + s.extent) * (1.0f / 4194304.0f) <= s.margin_floor) && s.n_faces != 0;   // also true for NaN
+  // (2^-21, not the 2^-22 of a single fma: the centre / half-extent form rounds a slab distance twice — t(centre), then -+ half * |1/d| —
+  // on top of the reciprocal's and -o/d's roundings: worst case about 1.75 (|origin| + |plane|) * 2^-22, bvh_builder.cpp)
+  const bool far_origin = !((cam_far + s.extent) * (1.0f / 2097152.0f) <= s.margin_floor) && s.n_faces != 0;   // also true for NaN
   if (far_origin) {
     if (which == PTAMD_KERNEL_BVH_RESTART) p.brute_walk = 1u;
     else which = PTAMD_KERNEL_BRUTE_FORCE;
@@ -360,10 +385,18 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats)
     for (auto& c : ctx->sample_scratch) if (c.stream == l->stream) sc = &c;
     if (!sc) {
       if (ctx->sample_scratch.size() >= kMaxScratchStreams) {
-        // a host cycling through short-lived streams: drop every scratch once nothing can be using them
+        // a host cycling through short-lived streams: drop every scratch once nothing can be using them — except those a captured
+        // graph has pinned (ptamd_release_captured frees them for this)
+        size_t pinned = 0;
+        for (auto& c : ctx->sample_scratch) pinned += c.captured ? 1u : 0u;
+        if (pinned >= kMaxScratchStreams) {
+          set_error("ptamd_raytrace: all 16 per-stream sample scratches of this context are pinned by captured graphs (ptamd_release_captured)");
+          return PTAMD_ERR_LIMIT;
+        }
         PT_HIP(hipDeviceSynchronize());
-        for (auto& c : ctx->sample_scratch) free_scratch(c);
-        ctx->sample_scratch.clear();
+        std::vector<ptamd_context::SampleScratch> kept;
+        for (auto& c : ctx->sample_scratch) { if (c.captured) kept.push_back(c); else free_scratch(c); }
+        ctx->sample_scratch.swap(kept);
       }
       ctx->sample_scratch.emplace_back();
       sc = &ctx->sample_scratch.back();
@@ -376,14 +409,14 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats)
   // side and the tail of one is covered by the bulk of the other, exactly what a host gets from two streams and
   // machine_share = 2.  Not when the caller runs its own pipeline (machine_share > 1), captures a graph or wants counters;
   // a host that waits for every frame gets whole-GPU launches on its own stream as before.
-  bool pipelined = ctx->overlap && which == PTAMD_KERNEL_BVH_RESTART && l->machine_share <= 1u && !stats;
+  bool pipelined = ctx->overlap && which == PTAMD_KERNEL_BVH_RESTART && (l->machine_share <= 1u || later_chunk) && !stats;
   bool capturing = false;
   if (stream != nullptr) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) capturing = true;
   }
-  if (capturing) pipelined = false;
-  if (pipelined) pipelined = sc->last_done != nullptr && hipEventQuery(sc->last_done) == hipErrorNotReady;
+  if (capturing || (sc && sc->no_pipeline) || l->no_pipelining) pipelined = false;
+  if (pipelined && !later_chunk) pipelined = sc->last_done != nullptr && hipEventQuery(sc->last_done) == hipErrorNotReady;
   // PTAMD_KERNEL_AUTO, one frame per launch (the reference's interactive loop, ptamd_raytrace) on an LDS-resident scene,
   // one launch at a time: the persistent kernel writes the surface itself, the restart kernel would add its resolve
   // pass to every launch (1080p, one launch per spp, one at a time: 6.03 vs 5.89 Gsamples/s).
@@ -526,7 +559,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats)
     // 6: 3.44 vs 3.92, 8: 2.89 vs 3.71); below that, whole-wave refill keeps primary rays coherent.
     p.refill_min = ctx->refill_min ? ctx->refill_min : (l->bounces >= 5 ? 16u : 64u);
     const uint32_t tiles_per_ticket = ctx->tiles_per_ticket;
-    const uint32_t share = overlap ? 2u : l->machine_share;
+    const uint32_t share = overlap ? (l->machine_share > 2u ? l->machine_share : 2u) : l->machine_share;
     if (share > 1u) n_blocks = n_blocks / share > 0u ? n_blocks / share : 1u;
     const uint32_t n_tickets = (p.n_tiles * count + tiles_per_ticket - 1u) / tiles_per_ticket;
     const uint32_t useful = (n_tickets + waves_per_block - 1u) / waves_per_block;
@@ -556,20 +589,40 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats)
         if (!sc->mega_done[i]) PT_HIP(hipEventCreateWithFlags(&sc->mega_done[i], hipEventDisableTiming));
         if (!sc->resolved[i]) PT_HIP(hipEventCreateWithFlags(&sc->resolved[i], hipEventDisableTiming));
       }
-      // The slabs a stream may use grow together: allocating synchronises, which must not happen when a host that had waited
-      // for its frames starts to run ahead, nor inside a graph capture that follows an eager launch of the same
-      // configuration.  The three pipelining slabs only for launches the library may pipeline (a caller that runs its own
-      // pipeline, machine_share > 1, never uses them: 4.8 GB per stream at 4K x 16 spp).
-      const bool may_pipeline = ctx->overlap && l->machine_share <= 1u && !stats;
-      for (uint32_t i = 0; i < 4u; ++i) {
-        if (need <= sc->bytes[i] || (!may_pipeline && i != 3u)) continue;
-        // launches of this stream (their megakernels possibly on the internal streams) are the only users of the old buffer
+      // Slab [3] belongs to launches that stay on the caller's stream; [0..2] exist only for streams whose launches the library
+      // has actually pipelined (a host that waits for every frame pays for ONE slab, not four).  Growing synchronises
+      // (the old buffer may be in use): it happens once per stream and configuration — for the pipelining slabs at the first launch
+      // that finds its predecessor still running, which costs that launch its overlap and no more.
+      auto grow = [&](uint32_t i) -> int {
         PT_HIP(hipStreamSynchronize(stream));
         for (hipStream_t is : ctx->internal) if (is) PT_HIP(hipStreamSynchronize(is));
         (void)hipFree(sc->buf[i]);
         sc->buf[i] = nullptr; sc->bytes[i] = 0;
-        PT_HIP(hipMalloc(reinterpret_cast<void**>(&sc->buf[i]), need));
+        hipError_t me = hipMalloc(reinterpret_cast<void**>(&sc->buf[i]), need);
+        if (me != hipSuccess) { sc->buf[i] = nullptr; (void)hipGetLastError(); return PTAMD_ERR_HIP; }
         sc->bytes[i] = need;
+        return PTAMD_OK;
+      };
+      if (overlap) {
+        bool ok = true;
+        for (uint32_t i = 0; i < 3u && ok; ++i) if (need > sc->bytes[i]) ok = grow(i) == PTAMD_OK;
+        if (!ok) {
+          // no room for the pipelining slabs: this stream renders unpipelined from now on (slab [3] on the caller's stream)
+          for (uint32_t i = 0; i < 3u; ++i) { (void)hipFree(sc->buf[i]); sc->buf[i] = nullptr; sc->bytes[i] = 0; }
+          sc->no_pipeline = true;
+          return do_launch(ctx, l_in, stats, later_chunk);
+        }
+      } else if (need > sc->bytes[3]) {
+        if (capturing) {
+          set_error("ptamd_raytrace: a launch cannot size its stream's sample slab inside a graph capture: issue this configuration once eagerly first");
+          return PTAMD_ERR_LIMIT;
+        }
+        if (sc->captured) {
+          set_error("ptamd_raytrace: a captured graph pins this stream's sample slab; a larger launch would reallocate it under the graph "
+                    "(ptamd_release_captured(ctx, stream) once the graph is gone)");
+          return PTAMD_ERR_LIMIT;
+        }
+        if (grow(3u) != PTAMD_OK) return hip_fail("hipMalloc of the sample slab", hipErrorOutOfMemory);
       }
       p.samples_out = sc->buf[slab];
       p.pool = reinterpret_cast<float4*>(reinterpret_cast<char*>(sc->buf[slab]) + sample_bytes);
@@ -581,7 +634,12 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats)
     p.walk_min4 = ctx->walk_min4;
     p.tiles_per_ticket = tiles_per_ticket;
     // tickets 0..n_waves-1 are taken statically by the waves; the shared counter hands out the rest
-    const uint32_t slot = ctx->ticket_next++ % kTicketRing;
+    uint32_t slot = ctx->ticket_next++ % kTicketRing;
+    for (uint32_t tries = 0; ctx->slot_pinned[slot]; ++tries) {   // slots baked into captured graphs are not handed out again
+      if (tries >= kTicketRing) { set_error("ptamd_raytrace: every ring slot of ticket heads is pinned by captured graphs (ptamd_release_captured)"); return PTAMD_ERR_LIMIT; }
+      slot = ctx->ticket_next++ % kTicketRing;
+    }
+    if (capturing && sc) { ctx->slot_pinned[slot] = true; sc->pinned_slots.push_back(slot); sc->captured = true; }
     p.tile_counter = ctx->d_tickets + slot;
     p.n_static = n_blocks * waves_per_block;
     if (split) PT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)p.n_static, 1, stream));
@@ -682,6 +740,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_heads), (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
   PT_HIP(hipMemset(ctx->d_heads, 0, (size_t)kTicketRing * 8u * PT_HEAD_STRIDE * sizeof(uint32_t)));
   ctx->heads_clean.assign(kTicketRing, true);
+  ctx->slot_pinned.assign(kTicketRing, false);
   {
     const char* e = tuning_env("PTAMD_GAMMA_TABLE"); // tuning knob: 0 = pt_powf for every pixel
     if (!e || std::atoi(e) != 0) {
@@ -798,7 +857,8 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   }
 
   Bvh bvh;
-  int rc = build_bvh(sc->faces, sc->n_faces, kBoxMargin, kMaxLeaf, bvh);
+  // (the quantised node forms only where their tuning knob is set: nothing else can select them)
+  int rc = build_bvh(sc->faces, sc->n_faces, kBoxMargin, kMaxLeaf, bvh, (ctx->wide8 ? kBvhForm8 : 0u) | (ctx->wide4q ? kBvhForm4q : 0u));
   if (rc != PTAMD_OK) return rc;
 
   // storage-order {e1,e2,v0,idx} records for the brute-force variant, and the shading records
@@ -868,8 +928,8 @@ int ptamd_upload_scene(ptamd_context* ctx, const ptamd_scene_desc* sc, uint32_t*
   for (ptamd_light& dl : dev_lights) dl.radius = dl.radius * dl.radius;
   if ((rc = upload(d.nodes, bvh.nodes.data(), bvh.nodes.size() * 4)) ||
       (rc = upload(d.nodes4, bvh.nodes4.data(), bvh.nodes4.size() * 4)) ||
-      (rc = upload(d.nodes8, bvh.nodes8.data(), bvh.nodes8.size() * 4)) ||
-      (rc = upload(d.nodes4q, bvh.nodes4q.data(), bvh.nodes4q.size() * 4)) ||
+      (bvh.nodes8.empty() ? 0 : (rc = upload(d.nodes8, bvh.nodes8.data(), bvh.nodes8.size() * 4))) ||
+      (bvh.nodes4q.empty() ? 0 : (rc = upload(d.nodes4q, bvh.nodes4q.data(), bvh.nodes4q.size() * 4))) ||
       (rc = upload_padded(d.tris_bvh, bvh.tris.data(), bvh.tris.size() * 4, 128)) ||   // (the merged wide walk reads eight 16-byte words from a leaf's first record)
       (rc = upload(d.tris_brute, brute.data(), brute.size() * 4)) ||
       (rc = upload(d.shade, shade.data(), shade.size() * 4)) ||
@@ -949,6 +1009,18 @@ int ptamd_raytrace(ptamd_context* ctx, void* surface_rgba8, uint32_t scene_id, u
 }
 
 int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch) { return do_launch(ctx, launch, false); }
+
+int ptamd_release_captured(ptamd_context* ctx, void* stream)
+{
+  if (!ctx) { set_error("ptamd_release_captured: null context"); return PTAMD_ERR_ARG; }
+  for (auto& c : ctx->sample_scratch) {
+    if (c.stream != stream) continue;
+    for (uint32_t slot : c.pinned_slots) { ctx->slot_pinned[slot] = false; ctx->heads_clean[slot] = false; }   // (a replay may have been cut short: clear before reuse)
+    c.pinned_slots.clear();
+    c.captured = false;
+  }
+  return PTAMD_OK;
+}
 
 int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_trace_stats* out)
 {

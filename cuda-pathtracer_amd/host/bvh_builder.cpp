@@ -268,7 +268,7 @@ inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 } // namespace
 
-int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t max_leaf, Bvh& out)
+int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t max_leaf, Bvh& out, uint32_t forms)
 {
   out = Bvh();
   float split_alpha = 0.0f;   // pre-splitting off unless asked for (tuning knobs)
@@ -278,6 +278,8 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
   if (n_faces == 0) return PTAMD_OK;
   if (n_faces >= (1u << 24)) { set_error("build_bvh: more than 2^24 faces"); return PTAMD_ERR_LIMIT; }
   if (const char* e = tuning_env("PTAMD_BVH_MAX_LEAF")) max_leaf = (uint32_t)std::atoi(e);   // tuning knobs
+  // (process-wide builder constants: back to their defaults on every build, so that a knob set for one build does not outlive it)
+  g_isect_cost = 1.6f; g_sweep_limit = 1u << 30;
   if (const char* e = tuning_env("PTAMD_BVH_ISECT_COST")) g_isect_cost = (float)std::atof(e);
   if (const char* e = tuning_env("PTAMD_BVH_SWEEP_LIMIT")) g_sweep_limit = (uint32_t)std::atoi(e);   // (2048: round 2's builder)
   if (max_leaf < 1) max_leaf = 1;
@@ -355,10 +357,14 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
     }
   }
 
-  // The slab test evaluates fma(plane, 1/d, -(o/d)): its rounding error, expressed as a distance, is about
-  // (|o| + |plane|) * 2^-22 per axis.  Bounce rays start on the scene's surfaces (|o| <= extent), so every box also
-  // gets extent * 2^-20 (4x that error); a camera much farther out than the scene is the launcher's business
-  // (ptamd_api.cpp: far-origin check against Bvh::margin_floor).
+  // The slab tests of the LDS loop and of the four-wide float walk form an axis' distances from the box's centre and half
+  // extent: tc = fma(c, 1/d, -(o/d)), then fma(-+h, |1/d|, tc).  Expressed as a displacement of the plane along the axis the
+  // roundings add up to: the reciprocal (v_rcp_f32, 1 ulp) (|o| + |p|) 2^-23, -(o/d) |o| 2^-24, tc (|o| + |c|) 2^-24 and the
+  // final fma (|o| + |p|) 2^-24 — at most (|o| + |p|) 2^-22 + |o| 2^-24 with an exact reciprocal, about 1.75 (|o| + |p|) 2^-22
+  // with a 2-ulp one.  (The box [c - h, c + h] itself contains [lo, hi] exactly: h is rounded up where the record is formed.)
+  // Bounce rays start on the scene's surfaces (|o| <= extent), so every box also gets extent * 2^-20 — 2.3x the worst case at
+  // |o| = |p| = extent — and |p| * 1e-6 on top; a camera much farther out than the scene is the launcher's business
+  // (ptamd_api.cpp: far-origin check, (|camera| + extent) * 2^-21 against Bvh::margin_floor).
   const float origin_margin = extent * (1.0f / 1048576.0f);
   out.extent = extent;
   out.all_finite = all_finite;
@@ -514,9 +520,9 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
     // ---- ... and the same four-wide nodes in 64 bytes (Bvh::nodes4q): child boxes as 8-bit planes on a per-node grid (float
     // origin, one power-of-two scale per axis), rounded outward.  Half the bytes and half the load instructions per visit.
     // The visiting order of an octant and of its opposite are each other's reverse: only octants 0..3 are stored.
-    out.nodes4q.assign((size_t)out.n_nodes4 * 16, 0u);
+    if (forms & kBvhForm4q) out.nodes4q.assign((size_t)out.n_nodes4 * 16, 0u);
     const float mq = margin + 2.0f * origin_margin;   // (two more roundings in the slab arithmetic than the float form: as for nodes8)
-    for (size_t w = 0; w < wide.size(); ++w) {
+    for (size_t w = 0; (forms & kBvhForm4q) && w < wide.size(); ++w) {
       uint32_t* q = &out.nodes4q[w * 16];
       float lo_c[4][3], hi_c[4][3];
       float nlo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, nhi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
@@ -607,7 +613,7 @@ int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t 
 
   // ---- the same tree once more, collapsed to EIGHT children per node with quantised child boxes (layout: ptamd_internal.h,
   // Bvh::nodes8): one 128-byte line per node again, half the node visits of the four-wide form.
-  {
+  if (forms & kBvhForm8) {
     // Which binary nodes become the children of a wide node is decided by the dynamic programme of Ylitie, Karras, Laine
     // 2017 (section 3.1) instead of round 2's greedy "open the largest child" rule, which left the bottom of the tree full of
     // wide nodes with two or three leaves (3.1 children per node on the atrium): cost[n][i] = cheapest SAH cost of

@@ -105,7 +105,10 @@ struct Bvh {
 
 
 // margin: absolute inflation added to every box face (see DESIGN.md "Conservative boxes")
-int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t max_leaf, Bvh& out);
+// forms: which of the knob-only node forms to build beside the binary tree and the four-wide float nodes (the eight-wide quantised
+// nodes take a dynamic programme over the whole tree; a production upload builds neither)
+constexpr uint32_t kBvhForm8 = 1u, kBvhForm4q = 2u;
+int build_bvh(const ptamd_face* faces, uint32_t n_faces, float margin, uint32_t max_leaf, Bvh& out, uint32_t forms = kBvhForm8 | kBvhForm4q);
 
 // Host traversal with the same structure the kernel uses (tests + stats cross-check).
 struct HostHit { int32_t kind; int32_t index; float t; float u, v; };

@@ -74,7 +74,7 @@ class Launch(C.Structure):
                 ("kernel", C.c_uint32), ("band_local_buffers", C.c_uint32), ("frame_count", C.c_uint32),
                 ("machine_share", C.c_uint32),
                 ("interleave_ranks", C.c_uint32), ("interleave_rank", C.c_uint32), ("interleave_rows", C.c_uint32),
-                ("reset_accumulation", C.c_uint32)]
+                ("reset_accumulation", C.c_uint32), ("no_pipelining", C.c_uint32)]
 
 
 class TraceStats(C.Structure):
@@ -134,6 +134,7 @@ SIGNATURES = {
     "ptamd_reset_frame_counter": (C.c_int, [C.c_void_p]),
     "ptamd_wang_hash": (C.c_uint32, [C.c_uint32]),
     "ptamd_interleaved_rows": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "ptamd_release_captured": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ptamd_raytrace_stats": (C.c_int, [C.c_void_p, C.POINTER(Launch), C.POINTER(TraceStats)]),
     "ptamd_scene_info_get": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(SceneInfo)]),
     "ptamd_set_timeline": (C.c_int, [C.c_void_p, C.c_uint32]),

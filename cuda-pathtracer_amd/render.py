@@ -117,7 +117,7 @@ class Context:
                     moved: bool = False, post_id: int = POST_NONE, stream=None,
                     rows: Optional[tuple] = None, kernel: int = N.KERNEL_AUTO,
                     band_local_buffers: bool = False, frame_count: int = 1, machine_share: int = 0,
-                    interleave: Optional[tuple] = None, reset_accumulation: bool = False) -> N.Launch:
+                    interleave: Optional[tuple] = None, reset_accumulation: bool = False, no_pipelining: bool = False) -> N.Launch:
         """interleave = (ranks, rank, band_rows): render the interleaved bands of `rank` (ptamd_launch.interleave_*)."""
         l = N.Launch()
         l.surface_rgba8 = _ptr(array)
@@ -135,10 +135,15 @@ class Context:
         if interleave is not None:
             l.interleave_ranks, l.interleave_rank, l.interleave_rows = interleave
         l.reset_accumulation = 1 if reset_accumulation else 0
+        l.no_pipelining = 1 if no_pipelining else 0
         return l
 
     def raytrace_ex(self, launch: N.Launch) -> None:
         N.check(self._lib.ptamd_raytrace_ex(self._h, C.byref(launch)))
+
+    def release_captured(self, stream=None) -> None:
+        """The graphs captured on `stream` are gone: its sample slab and ring slots are no longer pinned (ptamd_release_captured)."""
+        N.check(self._lib.ptamd_release_captured(self._h, _stream_handle(stream)))
 
     def raytrace_stats(self, launch: N.Launch) -> dict:
         st = N.TraceStats()

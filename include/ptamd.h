@@ -263,18 +263,28 @@ typedef struct {
    * accumulation only through `moved`); saves the clear and the read.  With frame_count = N it applies to the first
    * frame of the batch. */
   uint32_t reset_accumulation;
+  /* != 0: never pipeline this launch inside the library (below, "Back-to-back launches"): path-tracing kernel and resolve pass
+   * both run on launch->stream, sized to the whole GPU (or to machine_share), whatever the state of the stream.  0: the library
+   * decides per launch (it pipelines when the stream's previous launch is still running).  For hosts that want run-to-run
+   * identical launch shapes, e.g. under a profiler. */
+  uint32_t no_pipelining;
 } ptamd_launch;
 
 /* Asynchronous on launch->stream.  Once a configuration (frame size, frame_count, stream) has been launched once — the
  * first launch sizes that stream's sample scratch, which synchronises and allocates — later launches only enqueue
  * kernels and memsets, so a host may capture them into a hipGraph (hipStreamBeginCapture on launch->stream) and replay it:
  * tests/test_gpu_parity.py test_batched_launch_is_graph_capturable.  The captured launch keeps its frame_nb / seeds.
- * What a captured launch pins: its stream's in-stream sample slab and its ring slot of tile-ticket heads are baked into the
- * graph.  While the graph is alive the caller must not (a) issue a LARGER launch on that stream (the slab would be reallocated:
- * replays would write freed memory), (b) use more than 16 streams with batched launches on the context (the 17th drops every
- * slab), (c) let more than 1024 other launches of the context pass between two replays that may run concurrently with eager
- * launches (the ring slot comes round again).  Eager launches of the same or a smaller configuration on the same stream are
- * fine: stream order protects the slab, and launches the library pipelines (below) use slabs of their own.
+ * What a captured launch pins, and how the library enforces it: the stream's in-stream sample slab and the launch's ring slot of
+ * tile-ticket heads are baked into the graph.  From the capture on (until ptamd_release_captured for that stream)
+ *   - a launch on that stream that would need a LARGER slab returns PTAMD_ERR_LIMIT instead of reallocating it under the graph
+ *     (the same or smaller configurations, eager or captured, are fine: stream order protects the slab; launches the library
+ *     pipelines use slabs of their own);
+ *   - the ring slot is taken out of the rotation, so no later launch of the context shares its ticket heads with a replay;
+ *   - the stream's scratch survives the "17th stream" eviction (a context keeps at most 16 per-stream scratches; when all 16
+ *     are pinned the launch that needs a 17th returns PTAMD_ERR_LIMIT);
+ *   - a launch that would have to SIZE the slab inside the capture returns PTAMD_ERR_LIMIT (launch the configuration once eagerly).
+ * Memory per stream: one slab of rows x width x 12 bytes x min(frame_count, 4) (longer batches are issued as consecutive launches
+ * of four frames: same bits), plus three more of the same size once the library has pipelined launches of that stream.
  *
  * Back-to-back launches.  A host that issues launches of the default kernel on ONE stream without waiting for them (the
  * reference's render loop does not wait: gpu_processor.cpp:365-386) gets them pipelined by the library: when the stream's
@@ -284,6 +294,9 @@ typedef struct {
  * caller can see (accumulator, surface) is written on the caller's stream, in order.  Not applied when machine_share > 1 (the
  * caller runs its own pipeline), during graph capture, or for ptamd_raytrace_stats. */
 int ptamd_raytrace_ex(ptamd_context* ctx, const ptamd_launch* launch);
+/* Tells the library that the graphs captured on `stream` are gone (or will not be replayed any more): its sample slab may be
+ * reallocated again and its pinned ring slots return to the rotation.  PTAMD_OK also when nothing was pinned. */
+int ptamd_release_captured(ptamd_context* ctx, void* stream);
 /* Rows an interleaved launch renders (= rows its band-local buffers must hold): the bands j = rank, rank + ranks, ... of
  * band_rows rows each, the last band of the frame possibly shorter. */
 uint32_t ptamd_interleaved_rows(uint32_t height, uint32_t ranks, uint32_t rank, uint32_t band_rows);

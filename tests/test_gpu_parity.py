@@ -641,7 +641,9 @@ def test_far_camera_keeps_bvh_exact(P, O, gpu_ctx):
     c = rng.uniform(-1.0, 1.0, size=(n, 1, 3))
     tris = (c + rng.normal(scale=0.08, size=(n, 3, 3)) * np.float32([1.0, 1.0, 0.002])).astype(np.float32)   # thin in z
     cube = synthetic_cubemap(rng, 2)
-    for dist, fov in ((2.0e3, 0.002), (6.0e4, 0.00007)):
+    # (margin_floor = 1e-3 + extent * 2^-20 here: the launcher walks the tree up to (|camera| + extent) * 2^-21 <= margin_floor, i.e.
+    # about 2 097 units — 2 090 is just inside, 2 300 just outside, where every face is tested: ADVICE r3 on the two-step slab form)
+    for dist, fov in ((2.0e3, 0.002), (2.09e3, 0.002), (2.3e3, 0.002), (6.0e4, 0.00007)):
         hs = make_scene(P, tris, lights=[((0.0, 0.5, 2.0), (1.0, 0.9, 0.8), 4.0, 0.3)],
                         camera=dict(position=(0.0, 0.0, dist), dir=(0.0, 0.0, -1.0), fov_x=fov, aperture=0.0, focus_dist=dist))
         ref = O.render(O.OracleScene.from_host_scene(hs, cube), O.camera_from_record(hs.camera), 64, 48, spp=2, bounces=3)
@@ -1023,3 +1025,84 @@ def test_contracted_kernel_stays_inside_the_stated_tolerance(P, gpu_ctx, indoor)
     assert beyond <= TEXTURED_MAX_SHARE_BEYOND_1E4 and lsb <= TEXTURED_MAX_SHARE_BEYOND_1LSB and mean_delta <= TEXTURED_MAX_MEAN_IMAGE_DELTA, \
         (beyond, lsb, mean_delta)
     assert identical < 1.0
+
+
+def test_captured_launch_pins_its_slab_and_the_library_enforces_it(P, gpu_ctx, indoor):
+    """ptamd.h "What a captured launch pins": after a capture on a stream, a LARGER launch on that stream is refused
+    (PTAMD_ERR_LIMIT) instead of reallocating the slab under the graph; replays stay bit-identical; the same or a smaller
+    configuration is fine; ptamd_release_captured lifts the pin."""
+    needs_batched_default()
+    import torch
+    W, H, spp = 640, 360, 4
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    eager = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H)
+    eager.render(spp=spp, bounces=4, batched=True, reset=True)
+    torch.cuda.synchronize()
+    want = (eager.accum.cpu().numpy(), eager.surface.cpu().numpy())
+    fr = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H)
+    big = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), 2 * W, 2 * H)
+    small = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W // 2, H // 2)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fr.render(spp=spp, bounces=4, batched=True, reset=True, stream=side)     # sizes this stream's slab
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        fr.render(spp=spp, bounces=4, batched=True, reset=True, stream=torch.cuda.current_stream())
+    try:
+        with torch.cuda.stream(side):
+            # (a) a larger launch on the capture's stream would reallocate the slab the graph writes: refused
+            with pytest.raises(P.PtamdError) as err:
+                big.render(spp=spp, bounces=4, batched=True, reset=True, stream=side)
+            assert err.value.status == P.native.PTAMD_ERR_LIMIT and "captured" in str(err.value)
+            # (b) a smaller one is fine (stream order protects the slab)
+            small.render(spp=spp, bounces=4, batched=True, reset=True, stream=side)
+        torch.cuda.synchronize()
+        for rep in range(2):
+            fr.accum.fill_(7.0)
+            fr.surface.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *want, f"graph replay {rep} after a refused launch")
+    finally:
+        del g
+        torch.cuda.synchronize()
+        gpu_ctx.release_captured(side)
+    # (c) the pin is lifted: the larger launch goes through and renders what it should
+    with torch.cuda.stream(side):
+        big.render(spp=spp, bounces=4, batched=True, reset=True, stream=side)
+    torch.cuda.synchronize()
+    ref = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), 2 * W, 2 * H)
+    ref.render(spp=spp, bounces=4, batched=False, reset=True)
+    torch.cuda.synchronize()
+    assert_same(big.accum.cpu().numpy(), big.surface.cpu().numpy(), ref.accum.cpu().numpy(), ref.surface.cpu().numpy(), "after release")
+
+
+def test_long_batches_are_issued_four_frames_at_a_time(P, gpu_ctx, indoor):
+    """frame_count = N is N consecutive launches by contract; the library issues batches longer than four frames as consecutive
+    launches of four, so that a stream's sample slab does not grow with N: same bits as one launch per frame, and
+    no more device memory for 13 frames than for 4."""
+    needs_batched_default()
+    import torch
+    W, H = 480, 270
+    cube = P.cubemap_for_scene(indoor)
+    ids = (gpu_ctx.upload_scene(indoor), gpu_ctx.upload_cubemap(cube))
+    st = torch.cuda.Stream()
+    a = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H)
+
+    def batch(n):   # one call with frame_count = n, never pipelined by the library (so that the slabs in play do not depend on timing)
+        l = gpu_ctx.make_launch(a.surface, a.accum, *ids, indoor.camera_struct(), W, H, frame_nb=1, bounces=4, stream=st,
+                                kernel=P.KERNEL_AUTO, frame_count=n, reset_accumulation=True, no_pipelining=True)
+        with torch.cuda.stream(st):
+            gpu_ctx.raytrace_ex(l)
+        torch.cuda.synchronize()
+
+    batch(4)
+    free_after_4 = torch.cuda.mem_get_info()[0]
+    batch(13)
+    assert torch.cuda.mem_get_info()[0] >= free_after_4 - (1 << 20), "the sample slab grew with frame_count"
+    b = P.FrameRenderer(gpu_ctx, *ids, indoor.camera_struct(), W, H)
+    b.render(spp=13, bounces=4, batched=False, reset=True)
+    torch.cuda.synchronize()
+    assert_same(a.accum.cpu().numpy(), a.surface.cpu().numpy(), b.accum.cpu().numpy(), b.surface.cpu().numpy(), "13 frames: batched vs one launch per frame")
