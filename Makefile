@@ -5,7 +5,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 # -ffp-contract=off: the kernel must execute the reference's IEEE op sequence
 # -fno-slp-vectorize -fno-vectorize: packed f32 VALU ops issue at half rate on gfx950 and the packing costs v_mov
-#   shuffles and spills; scalar code is 6.8 % faster (scripts/gpu_flags.sh)
+#   shuffles and spills; scalar code is 6.8 % faster (round 2; re-run: scripts/build_variants.sh + scripts/gpu_ab.sh)
 HIPFLAGS := $(EXTRA_HIPFLAGS) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-vectorize -Iinclude -I$(PKG)/host -I$(PKG)/csrc \
             -Wall -Wextra -Wno-unused-parameter
 LIB      := $(PKG)/libptamd.so

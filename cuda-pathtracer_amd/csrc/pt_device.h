@@ -38,7 +38,7 @@ PT_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x 
 PT_DEV f3 normalize(f3 v) { float inv_len = 1.0f / __builtin_sqrtf(dot(v, v)); return v * inv_len; }
 
 #ifndef PT_SHORT_MATH
-#define PT_SHORT_MATH 1   /* 0: the compiler's full sqrt / division everywhere (A/B: scripts/gpu_r2_wg.sh "x=-DPT_SHORT_MATH=0") */
+#define PT_SHORT_MATH 1   /* 0: the compiler's full sqrt / division everywhere (A/B: scripts/build_variants.sh x="-DPT_SHORT_MATH=0" + scripts/gpu_ab.sh) */
 #endif
 // ---- short forms of the two IEEE operations the shading code is full of.  Each is the compiler's own expansion minus
 // the steps that are the identity inside a range; scripts/ubench/sqrt_exact.hip and rcp_exact.hip compare them with the

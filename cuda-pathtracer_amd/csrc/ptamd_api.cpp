@@ -122,7 +122,7 @@ struct ptamd_context {
   bool default_kernel_is_builtin = true;              // false once PTAMD_DEFAULT_KERNEL pinned it
   uint32_t refill_min = 0; // 0 = choose per launch (see do_launch); PTAMD_REFILL_MIN pins it
   // restart kernel: a round of walks ends once fewer than min(round_min, entering lanes / round_div) lanes are unfinished
-  // measured (scripts/gpu_r2_sweep.sh, 1080p x 4 spp x 4 bounces): round_min 16-32 and walk_min 4-6 are a flat optimum
+  // measured (round 2 sweep, 1080p x 4 spp x 4 bounces; re-run with scripts/gpu_ab.sh): round_min 16-32 and walk_min 4-6 are a flat optimum
   uint32_t round_min = 16, round_div = 4; // PTAMD_ROUND_MIN, PTAMD_ROUND_DIV
   uint32_t walk_min = 7;                  // restart kernel: a box phase ends once fewer lanes than this still walk (PTAMD_WALK_MIN; 4 / 5 / 7 / 8 / 10 / 12: 9331 / 9372 / 9405 / 9377 / 9338 / 9273 Msamples/s with the final shading code)
   bool pool_in_lds = true;                // restart kernel: pools of fresh paths in LDS when they fit (PTAMD_POOL_LDS=0: always the global slab)
@@ -152,7 +152,7 @@ constexpr float kQuantisedMaxExtent = 1.0e8f;   // largest |coordinate| of a sce
 constexpr uint32_t kCompactMaxTris = 2047;   // a leaf's link code holds count << 11 | first triangle record in 15 bits (stage_scene)
 constexpr size_t kShadeFloats = 28;   // 7 float4 per face (pt_kernels.hip: resolve_hit).  Round 4 re-measured on the atrium: a 128-byte stride (one line per record) -1.2 %, a 64-byte hot half + 64-byte cold half (one line, 17 MB instead of 30) level, -0.6 % on textured scenes (profiles/r04_notes.md)
 constexpr float kBoxMargin = 1e-3f; // absolute box inflation, DESIGN.md "Conservative boxes"
-constexpr uint32_t kMaxLeaf = 2;   // 2 / 3 / 4 = 10902 / 10839 / 10160 Msamples/s on the headline now that a box test costs 16 VALU and a triangle test ~67 (scripts/gpu_r3_leaf2.sh: every bench configuration >= leaves of three)
+constexpr uint32_t kMaxLeaf = 2;   // 2 / 3 / 4 = 10902 / 10839 / 10160 Msamples/s on the headline now that a box test costs 16 VALU and a triangle test ~67 (round 3, PTAMD_BVH_MAX_LEAF sweep: every bench configuration >= leaves of three)
 constexpr uint32_t kTicketRing = 1024;
 constexpr size_t kMaxScratchStreams = 16;   // sample scratches kept per context (one per stream that batches frames)
 constexpr uint32_t kMaxFramesPerSlab = 4;   // a batched launch parks at most this many frames at a time: longer batches are issued as consecutive launches of <= 4 frames (the same bits by the contract of frame_count), so a stream's slab bytes do not depend on frame_count
