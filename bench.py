@@ -53,6 +53,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WIDTH, HEIGHT, SPP, BOUNCES = 1920, 1080, 4, 4
+MAX_FRAMES_PER_LAUNCH = 4   # ptamd_api.cpp: kMaxFramesPerSlab — a batch of more frames is issued as consecutive launches of four
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 N_SIMDS, CLOCK_GHZ, VALU_CYCLES = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles
 VALU_PEAK_GINST = N_SIMDS * CLOCK_GHZ / VALU_CYCLES   # 1228.8 G wave-instructions/s
@@ -215,6 +216,20 @@ KERNEL_SYMBOL = {"persistent": "pt_megakernel_persistent", "restart": "pt_megake
                  "split": "pt_megakernel_split", "bvh": "pt_megakernel", "brute": "pt_megakernel"}
 
 
+_STREAMS = {}
+
+
+def frame_stream(torch, dev, i):
+    """The i-th frames-in-flight stream of this process, created once and shared by every Workload: HIP deals streams to its
+    hardware queues in creation order, and a bench run builds a dozen workloads (each with a context that owns two internal
+    streams) — the 2 + 2 + ... streams of later workloads can land pairwise on ONE queue, where the two frames in flight then
+    serialise (round 4: crate_land 14.4 -> 9.5 Gsamples/s inside the full run, 14.4 alone)."""
+    key = (str(dev), i)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _STREAMS[key]
+
+
 class Workload:
     """A frame configuration on this rank: scene uploaded once, `n_slots` frames in flight (buffers + stream each)."""
 
@@ -252,13 +267,13 @@ class Workload:
             fr = P.FrameRenderer(self.ctx, self.sid, self.cid, hs.camera_struct(), W, H, rows=(self.y0, self.y1),
                                  band_local=True, machine_share=(machine_share if machine_share > 0 else n_slots) if (share and n_slots > 1) else 0, interleave=interleave,
                                  surface=bg.send_rows() if bg is not None else None)
-            st = torch.cuda.current_stream() if n_slots == 1 else torch.cuda.Stream(device=self.dev)
+            st = torch.cuda.current_stream() if n_slots == 1 else frame_stream(torch, self.dev, i)
             self.slots.append((fr, bg, st))
         self.counter = 0
 
     @property
     def frames_per_launch(self):
-        return self.spp if self.batched else 1
+        return min(self.spp, MAX_FRAMES_PER_LAUNCH) if self.batched else 1
 
     def step(self, ev=None, gather=True):
         torch = self.torch
@@ -484,7 +499,7 @@ def main():
     dt, step_ms = wl.run(args.steps, args.warmup, args.settle_ms)
     gather_ms = wl.gather_ms() if (world > 1 or force_gather) else None
     frames_per_launch = wl.frames_per_launch
-    launches_per_step = spp // frames_per_launch
+    launches_per_step = -(-spp // frames_per_launch)
     # one step = launches_per_step megakernel launches (+ the small resolve kernel when batched) back to back on its stream
     kern_ms = step_ms / launches_per_step
     value = W * (wl.my_rows if proxy else H) * spp * args.steps / dt / 1e6
@@ -556,11 +571,14 @@ def main():
                 # the counters of THIS workload on THIS build (scripts/gpu_round4.sh collects one record per bench configuration);
                 # a record of another build prices nothing: pmc_stale
                 bid = P.native.load().ptamd_build_id().decode()
-                opmc = load_pmc(os.path.join(os.path.dirname(args.pmc_json), pmc_file), "restart", w2, h2, s2, b2, s2, 1, pmc_scene, bid)
+                fpl2 = min(s2, MAX_FRAMES_PER_LAUNCH)          # frames per megakernel launch, launches per step
+                lps2 = -(-s2 // fpl2)
+                opmc = load_pmc(os.path.join(os.path.dirname(args.pmc_json), pmc_file), "restart", w2, h2, s2, b2, fpl2, 1, pmc_scene, bid)
                 others.append({"workload": name, "value": round(w2 * h2 * s2 * k / odt / 1e6, 3), "unit": "Msamples/s",
-                               "steps": k, "ms_per_step": round(odt / k * 1e3, 4), "kernel_ms_per_launch": round(o_ms, 4),
+                               "steps": k, "ms_per_step": round(odt / k * 1e3, 4), "kernel_ms_per_launch": round(o_ms / lps2, 4),
+                               "launches_per_step": lps2, "frames_per_launch": fpl2,
                                "frames_in_flight": 2, "faces": oi["n_faces"], "bvh_nodes": oi["n_nodes"],
-                               "roofline": roofline_block(opmc, KERNEL_SYMBOL["restart"], o_ms, 2, w2 * h2 * s2, 28 * w2 * h2 * s2 + sc.scene_bytes(), bid)})
+                               "roofline": roofline_block(opmc, KERNEL_SYMBOL["restart"], o_ms / lps2, 2, w2 * h2 * fpl2, 28 * w2 * h2 * fpl2 + sc.scene_bytes(), bid)})
             extra["other_configs"] = others
 
     if rank == 0:

@@ -48,7 +48,7 @@ for f in glob.glob(os.path.join(out_dir, "pass*", "**", "*counter_collection.csv
 res = {c: s[0] / s[1] for c, s in acc.items()}
 res["_dispatches"] = {c: s[1] for c, s in acc.items()}
 batched = (not bargs.sequential) and kernel in ("persistent", "split", "restart") and bargs.spp > 1
-fpl = bargs.spp if batched else 1
+fpl = min(bargs.spp, 4) if batched else 1   # (ptamd_api.cpp: kMaxFramesPerSlab — longer batches are issued four frames per launch)
 samples = bargs.width * bargs.height * fpl
 d = {"samples_per_launch": samples}
 if res.get("SQ_ACTIVE_INST_VALU"):
