@@ -1255,6 +1255,38 @@ PT_DEV uint2 stack4_read(const Stack4& s, uint32_t k)
   return s.spill[(size_t)(k - s.lds_entries) * 64u];
 }
 
+#ifndef PT_POP_BATCH
+#define PT_POP_BATCH 1          /* pops after a leaf read four stack entries per LDS round trip (stack4_pop4) */
+#endif
+// The pop that follows a leaf.  A hit has usually just shortened the ray, so most of what the lane stacked on its way down lies
+// beyond it now: the plain loop below discards those entries one LDS round trip at a time (a leaf phase of the atrium took 7 000
+// cycles, most of them here: profiles/r04_notes.md).  This form reads the four entries under the top in ONE round trip and takes
+// the first whose distance does not lie beyond the best hit; entries in the global continuation of the stack go one by one.
+// (Used after leaves only: behind the hand-scheduled visit, whose pop already has its first entry read ahead, the same loop
+// measured -2 % against the visit's own one-entry-at-a-time asm loop.)
+PT_DEV uint32_t stack4_pop4(const Stack4& s, uint32_t& sp, float best_t)
+{
+  const LdsU2 col = stack4_lds(s);
+  while (sp > 0u) {
+    if (sp > s.lds_entries) {   // top of the stack is in the global continuation
+      --sp;
+      const uint2 e = s.spill[(size_t)(sp - s.lds_entries) * 64u];
+      if (u_as_f(e.y) <= best_t) return e.x;
+      continue;
+    }
+    // entries sp - 1 .. sp - 4 (indices below 0 read entry 0 again: never taken, the count says so)
+    const uint32_t i0 = sp - 1u, i1 = sp >= 2u ? sp - 2u : 0u, i2 = sp >= 3u ? sp - 3u : 0u, i3 = sp >= 4u ? sp - 4u : 0u;
+    pt_u2v e0 = col[i0 * 64u], e1 = col[i1 * 64u], e2 = col[i2 * 64u], e3 = col[i3 * 64u];
+    asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));   // (all four reads before the first compare)
+    if (u_as_f(e0.y) <= best_t) { sp = i0; return e0.x; }
+    if (sp >= 2u && u_as_f(e1.y) <= best_t) { sp = i1; return e1.x; }
+    if (sp >= 3u && u_as_f(e2.y) <= best_t) { sp = i2; return e2.x; }
+    if (sp >= 4u && u_as_f(e3.y) <= best_t) { sp = i3; return e3.x; }
+    sp = sp >= 4u ? sp - 4u : 0u;
+  }
+  return PT_NONE;
+}
+
 // Next reference whose entry distance does not lie beyond the best hit (PT_NONE: the stack is empty — walk over).
 PT_DEV uint32_t stack4_pop(const Stack4& s, uint32_t& sp, float best_t)
 {
@@ -1278,19 +1310,11 @@ PT_DEV uint32_t stack4_pop(const Stack4& s, uint32_t& sp, float best_t)
 // write disjoint lanes), so the treelet's LDS latency — bank conflicts included — came AFTER the memory latency in every box
 // iteration of the wave (profiles/r04_notes.md).  Loads only write the lanes EXEC enables, so no order is needed.
 typedef float pt_f4v __attribute__((ext_vector_type(4)));
-#define PT_TREELET_PLANE_BYTES_1 8192
-#define PT_TREELET_PLANE_BYTES_2 16384
-#define PT_TREELET_PLANE_BYTES_3 24576
-#define PT_TREELET_PLANE_BYTES_4 32768
-#define PT_TREELET_PLANE_BYTES_5 40960
-#define PT_TREELET_PLANE_BYTES_6 49152
-#define PT_TREELET_PLANE_BYTES_7 57344
-static_assert(PT_TREELET_STRIDE * 16u == PT_TREELET_PLANE_BYTES_1, "fetch_node4's plane offsets follow PT_TREELET_STRIDE");
-// `ahead`: the lane's top stack entry (entry sp - 1 of its LDS column), read with the node: a visit that hits nothing continues there.
+template <uint32_t PLANE_BYTES = PT_TREELET_STRIDE * 16u>   /* bytes between the chunk planes of the treelet */
 PT_DEV void fetch_node4(const float4* nodes4, const Stack4& stk, uint32_t cur, uint32_t sp, pt_f4v& r0, pt_f4v& r1, pt_f4v& r2, pt_f4v& r3, pt_f4v& r4,
                         pt_f4v& r5, pt_f4v& r6, pt_f4v& r7, pt_u2v& ahead)
 {
-  static_assert(PT_TREELET_STRIDE * 16u * 7u < 65536u, "chunk plane offsets must fit a ds_read offset field");
+  static_assert(PLANE_BYTES * 7u < 65536u, "chunk plane offsets must fit a ds_read offset field");
   const unsigned long long ga = (unsigned long long)(uintptr_t)nodes4 + ((unsigned long long)cur << 7);
   const uint32_t la = (uint32_t)(uintptr_t)stk.top + (cur << 4);
   const uint32_t pa = (uint32_t)(uintptr_t)stk.lds + ((sp - 1u) << 9);   // (sp == 0: an address below the column — whatever is there is never used)
@@ -1309,18 +1333,20 @@ PT_DEV void fetch_node4(const float4* nodes4, const Stack4& stk, uint32_t cur, u
       "global_load_dwordx4 %[r7], %[ga], off offset:112\n\t"
       "s_andn2_b64 exec, %[save], exec\n\t"                 // EXEC = the treelet's lanes of the visit
       "ds_read_b128 %[r0], %[la]\n\t"
-      "ds_read_b128 %[r1], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_1) "\n\t"
-      "ds_read_b128 %[r2], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_2) "\n\t"
-      "ds_read_b128 %[r3], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_3) "\n\t"
-      "ds_read_b128 %[r4], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_4) "\n\t"
-      "ds_read_b128 %[r5], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_5) "\n\t"
-      "ds_read_b128 %[r6], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_6) "\n\t"
-      "ds_read_b128 %[r7], %[la] offset:" PT_STR(PT_TREELET_PLANE_BYTES_7) "\n\t"
+      "ds_read_b128 %[r1], %[la] offset:%[p1]\n\t"
+      "ds_read_b128 %[r2], %[la] offset:%[p2]\n\t"
+      "ds_read_b128 %[r3], %[la] offset:%[p3]\n\t"
+      "ds_read_b128 %[r4], %[la] offset:%[p4]\n\t"
+      "ds_read_b128 %[r5], %[la] offset:%[p5]\n\t"
+      "ds_read_b128 %[r6], %[la] offset:%[p6]\n\t"
+      "ds_read_b128 %[r7], %[la] offset:%[p7]\n\t"
       "s_mov_b64 exec, %[save]\n\t"
       "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
       : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5), [r6] "=&v"(r6), [r7] "=&v"(r7),
         [ah] "=&v"(ahead), [save] "=&s"(save)
-      : [topn] "s"(stk.top_n), [cur] "v"(cur), [la] "v"(la), [ga] "v"(ga), [pa] "v"(pa)
+      : [topn] "s"(stk.top_n), [cur] "v"(cur), [la] "v"(la), [ga] "v"(ga), [pa] "v"(pa),
+        [p1] "i"(PLANE_BYTES), [p2] "i"(2u * PLANE_BYTES), [p3] "i"(3u * PLANE_BYTES), [p4] "i"(4u * PLANE_BYTES), [p5] "i"(5u * PLANE_BYTES),
+        [p6] "i"(6u * PLANE_BYTES), [p7] "i"(7u * PLANE_BYTES)
       : "vcc", "scc", "memory");
 }
 #ifndef PT_ASM_SELECT
@@ -1425,7 +1451,7 @@ PT_DEV uint32_t walk4_select_asm(const Stack4& stk, const Walk& w, unsigned long
 PT_DEV uint32_t walk4_compute(float4 lx, float4 ly, float4 lz, float4 hx, float4 hy, float4 hz, uint4 refs, uint4 ord, const Stack4& stk, const Walk& w, uint32_t& sp);
 
 // Visits interior node `cur`: fetches it (LDS treelet or L2), then walk4_compute.
-template <bool STATS>
+template <bool STATS, uint32_t PLANE_BYTES = PT_TREELET_STRIDE * 16u>
 PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk& w, uint32_t cur, uint32_t& sp, Counters* cnt = nullptr)
 {
   float4 lx, ly, lz, hx, hy, hz;
@@ -1436,7 +1462,7 @@ PT_DEV uint32_t walk4_visit(const float4* nodes4, const Stack4& stk, const Walk&
     long long tv0 = 0;
     if (STATS) tv0 = clock64();
     pt_u2v ahead;
-    fetch_node4(nodes4, stk, cur, sp, r0, r1, r2, r3, r4, r5, r6, r7, ahead);
+    fetch_node4<PLANE_BYTES>(nodes4, stk, cur, sp, r0, r1, r2, r3, r4, r5, r6, r7, ahead);
     if (STATS && cnt) { const long long tv1 = clock64(); if (PT_WAVE_ONE()) cnt->cyc[6] += (unsigned long long)(tv1 - tv0); }
 #if PT_ASM_SELECT
     // Usual case, decided for the whole wave: four more entries fit into the LDS part of every lane's stack (then every entry a pop
@@ -1791,7 +1817,7 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
         }
       if (STATS) cnt.tris += count < 3u ? count : 3u;
       if (count > 3u) walk_leaf<STATS>(tris, w, first + 3u, count - 3u, cnt.tris, cnt.wave_tri_iters, small_det, TS);
-      cur = stack4_pop(stk, sp, w.best.t);
+      cur = PT_POP_BATCH ? stack4_pop4(stk, sp, w.best.t) : stack4_pop(stk, sp, w.best.t);
     }
     if (STATS && PT_WAVE_ONE()) cnt.cyc[2] += (unsigned long long)(clock64() - tb1);
     if ((uint32_t)__popcll(__ballot(cur != PT_NONE)) < t_eff) break;
@@ -2538,6 +2564,98 @@ __global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(PT_KERNEL_PARAMS
   out[i] = make_int4(kind, index, (int)f_as_u(nr.t), 0);
 }
 
+// ---------------------------------------------------------------- walk-only kernel fed from a ray queue (round 4)
+//
+// The four-wide walk WITHOUT a path around it: persistent waves pull rays {dir, origin} from a global queue, walk them with the
+// same visit code as the restart kernel (fetch_node4 / walk4_select_asm, chunk-major LDS treelet, per-lane LDS stack with a global
+// continuation) and write {kind, index, t bits} records.  A lane whose walk ends takes the next ray as soon as `refill_min` lanes
+// of its wave are idle: no rounds, no shading, no path state — ~20 VGPRs less than the restart kernel, so the SAME walk can be
+// measured at 4, 5 and 6 waves per SIMD (template parameters: workgroup size, waves per SIMD the register budget aims for, nodes
+// per treelet plane).  A measurement hook (ptamd_trace_rays_queue; scripts/gpu_trace_queue.py; profiles/r04_notes.md): it is what
+// showed that the LDS part of the stack, not the number of waves, was what the wide walk was short of.
+template <int THREADS, int WPE, uint32_t PLANE_NODES>
+__global__ void __launch_bounds__(THREADS, WPE) pt_trace_queue_kernel(PT_KERNEL_PARAMS, const float* rays, uint32_t n, int4* out, uint32_t* head)
+{
+  extern __shared__ float4 s_mem[];
+  constexpr uint32_t PLANE_BYTES = PLANE_NODES * 16u;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t gwave = blockIdx.x * (THREADS / 64u) + (threadIdx.x >> 6);
+  for (uint32_t i = threadIdx.x; i < p.treelet_nodes * 8u; i += THREADS) s_mem[(i & 7u) * PLANE_NODES + (i >> 3)] = p.nodes4[i];
+  __syncthreads();
+  Stack4 stk;
+  stk.top = s_mem;
+  stk.top_n = p.treelet_nodes;
+  stk.lds = reinterpret_cast<uint2*>(s_mem + (p.treelet_nodes ? 8u * PLANE_NODES : 0u)) + (size_t)(threadIdx.x >> 6) * p.stack_lds_entries * 64u + lane;
+  stk.spill = p.stack_spill + (size_t)gwave * p.stack_spill_entries * 64u + lane;
+  stk.lds_entries = p.stack_lds_entries;
+  Counters cnt = {};
+  Walk w;
+  walk_init(w, mk3(0.f), mk3(0.f, 0.f, 1.f), 1u);
+  uint32_t cur = PT_NONE, sp = 0u, ray = PT_NONE;
+  uint32_t chunk_next = 0u, chunk_end = 0u;   // wave-uniform: the rays [chunk_next, chunk_end) of the queue are this wave's to hand out
+  bool exhausted = false;
+  const bool small_det = false;   // caller-supplied directions need not be unit vectors
+  for (;;) {
+    // ---- lanes without a ray take the next ones of the wave's chunk of the queue (one atomic per 512 rays: a single counter
+    // hands out ~88 tickets per microsecond chip-wide, MI355X_MICROARCH.md — per-refill atomics capped the kernel at 2.8 Grays/s)
+    const unsigned long long idle = __ballot(ray == PT_NONE);
+    const uint32_t n_idle = (uint32_t)__popcll(idle);
+    if (!exhausted && n_idle != 0u && (n_idle >= p.refill_min || n_idle == 64u)) {
+      if (chunk_next >= chunk_end) {
+        uint32_t base = 0u;
+        if (lane == 0u) base = atomicAdd(head, 512u);
+        chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        chunk_end = chunk_next + 512u < n ? chunk_next + 512u : n;
+        if (chunk_next >= n) { exhausted = true; chunk_next = chunk_end = n; }
+      }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      if (ray == PT_NONE && chunk_next + rank < chunk_end) {
+        ray = chunk_next + rank;
+        const float* r = rays + (size_t)ray * 6u;
+        walk_init(w, mk3(r[3], r[4], r[5]), mk3(r[0], r[1], r[2]), 1u);
+        cur = p.n_nodes4 ? 0u : PT_NONE;
+        sp = 0u;
+      }
+      chunk_next = chunk_next + n_idle < chunk_end ? chunk_next + n_idle : chunk_end;
+    }
+    if (__ballot(ray != PT_NONE) == 0ull) break;
+    if (ray != PT_NONE) {
+      w.oct_x = __ballot((w.oct & 1u) != 0u); w.oct_y = __ballot((w.oct & 2u) != 0u); w.oct_z = __ballot((w.oct & 4u) != 0u);
+      // box phase
+      for (;;) {
+        const bool interior = cur < PT_LEAF_BIT;
+        const uint32_t walkers = (uint32_t)__popcll(__ballot(interior));
+        if (walkers == 0u) break;
+        if (interior) cur = walk4_visit<false, PLANE_BYTES>(p.nodes4, stk, w, cur, sp);
+        if (walkers < p.walk_min4) break;
+      }
+      // leaf phase
+      if (cur != PT_NONE && (cur & PT_LEAF_BIT)) {
+        const uint32_t first = cur & 0xFFFFFFu, count = (cur >> 24) & 0x7Fu;
+        const float4* t = p.tris_bvh + (size_t)first * 3u;
+        float4 r[9];
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k)
+          if (k < count) { r[3 * k] = t[3 * k]; r[3 * k + 1] = t[3 * k + 1]; r[3 * k + 2] = t[3 * k + 2]; }
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k)
+          if (k < count) mt_test<false>(r[3 * k], r[3 * k + 1], r[3 * k + 2], w.o, w.d, w.best, small_det);
+        if (count > 3u) walk_leaf<false>(p.tris_bvh, w, first + 3u, count - 3u, cnt.tris, cnt.wave_tri_iters, small_det);
+        cur = PT_POP_BATCH ? stack4_pop4(stk, sp, w.best.t) : stack4_pop(stk, sp, w.best.t);
+      }
+      if (cur == PT_NONE) {   // the walk is over: light spheres, the record, and the lane is free again
+        Nearest nr;
+        nr.t = w.best.t; nr.u = w.best.u; nr.v = w.best.v; nr.idx = w.best.idx;
+        nr = nearest_lights(p, w.o, w.d, nr);
+        const int kind = nr.idx == PT_END ? 0 : ((nr.idx & PT_LIGHT) ? 2 : 1);
+        const int index = kind == 0 ? -1 : (int)(nr.idx & ~PT_LIGHT);
+        out[ray] = make_int4(kind, index, (int)f_as_u(nr.t), 0);
+        ray = PT_NONE;
+      }
+    }
+  }
+}
+
 // Nearest-hit query on explicit rays (tests: BVH vs brute force on the device).
 template <int KIND>
 __global__ void __launch_bounds__(256) pt_trace_rays_kernel(PT_KERNEL_PARAMS, const float* rays, uint32_t n, int4* out)
@@ -2823,6 +2941,41 @@ hipError_t resolve_kernels()
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
+}
+
+// config: 0 = 16 waves x 1 workgroup per CU (4 waves per SIMD) with a 512-node treelet, 1 = 10 x 2 (5) with 256 nodes each,
+// 2 = 12 x 2 (6) with 256 nodes each, 3 = 16 x 1 (4) with a 256-node treelet (the treelet's share of the difference)
+static const void* trace_queue_entry(uint32_t config, uint32_t* threads, uint32_t* plane_nodes, uint32_t* blocks_per_cu)
+{
+  switch (config) {
+    case 1: *threads = 640; *plane_nodes = 256; *blocks_per_cu = 2; return reinterpret_cast<const void*>(pt_trace_queue_kernel<640, 5, 256>);
+    case 2: *threads = 768; *plane_nodes = 256; *blocks_per_cu = 2; return reinterpret_cast<const void*>(pt_trace_queue_kernel<768, 6, 256>);
+    case 3: *threads = 1024; *plane_nodes = 256; *blocks_per_cu = 1; return reinterpret_cast<const void*>(pt_trace_queue_kernel<1024, 4, 256>);
+    default: *threads = 1024; *plane_nodes = 512; *blocks_per_cu = 1; return reinterpret_cast<const void*>(pt_trace_queue_kernel<1024, 4, 512>);
+  }
+}
+
+void trace_queue_shape(uint32_t config, uint32_t* threads, uint32_t* plane_nodes, uint32_t* blocks_per_cu)
+{
+  (void)trace_queue_entry(config, threads, plane_nodes, blocks_per_cu);
+}
+
+hipError_t launch_trace_queue(const KParams& p, uint32_t config, size_t lds_bytes, uint32_t n_blocks, const float* rays_dev, uint32_t n, int4* out_dev,
+                              uint32_t* head_dev, int* resident_blocks_per_cu, hipStream_t stream)
+{
+  uint32_t threads, plane, bpc;
+  const void* fn = trace_queue_entry(config, &threads, &plane, &bpc);
+  if (resident_blocks_per_cu && lds_bytes > 64 * 1024) {   // (first launch of a configuration: attribute and occupancy query)
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  if (resident_blocks_per_cu) {
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(resident_blocks_per_cu, fn, (int)threads, lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  KParams pc = p;
+  void* args[] = { &pc, &rays_dev, &n, &out_dev, &head_dev };
+  return hipLaunchKernel(fn, dim3(n_blocks), dim3(threads), args, lds_bytes, stream);
 }
 
 hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,

@@ -33,6 +33,10 @@ hipError_t build_gamma_table(float* table_dev, hipStream_t stream);
 hipError_t launch_gamma_selftest(const float* table_dev, uint32_t first, uint32_t count, unsigned long long* out_dev, hipStream_t stream);
 // Resolves every kernel entry point of the code object (setupFunctionTables' role: fail early when the device image is unusable).
 hipError_t resolve_kernels();
+// walk-only kernel fed from a ray queue (pt_kernels.hip: pt_trace_queue_kernel): shape of a configuration, launch
+void trace_queue_shape(uint32_t config, uint32_t* threads, uint32_t* plane_nodes, uint32_t* blocks_per_cu);
+hipError_t launch_trace_queue(const KParams& p, uint32_t config, size_t lds_bytes, uint32_t n_blocks, const float* rays_dev, uint32_t n, int4* out_dev,
+                              uint32_t* head_dev, int* resident_blocks_per_cu, hipStream_t stream);
 hipError_t launch_trace_rays(const KParams& p, int kind, const float* rays_dev, uint32_t n, int4* out_dev,
                              hipStream_t stream);
 

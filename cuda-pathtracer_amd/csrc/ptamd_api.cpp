@@ -116,6 +116,8 @@ struct ptamd_context {
   bool overlap = true;                    // PTAMD_OVERLAP=0 (tuning): everything on the caller's stream
   bool wide4q = false;                    // PTAMD_WIDE4Q=1 (tuning): big scenes walk the 64-byte quantised four-wide nodes instead of the float ones (ahead by 2.8 % while the walk's LDS accesses went out as FLAT instructions, level since they are LDS instructions: profiles/r03_notes.md)
   bool wide8 = false;                     // PTAMD_WIDE8=1 (tuning): big scenes walk the eight-wide quantised nodes (measured 8 % slower: DESIGN.md §4)
+  uint2* d_trace_spill = nullptr;             // ptamd_trace_rays_queue: global continuation of the walk-only kernel's stacks (grown on demand)
+  size_t trace_spill_bytes = 0;
   unsigned long long* d_timeline = nullptr;   // ptamd_set_timeline: 4 time stamps per wave of the restart kernel
   uint32_t timeline_waves = 0;
   uint32_t default_kernel = PTAMD_KERNEL_BVH_RESTART; // what PTAMD_KERNEL_AUTO means
@@ -126,6 +128,9 @@ struct ptamd_context {
   uint32_t round_min = 16, round_div = 4; // PTAMD_ROUND_MIN, PTAMD_ROUND_DIV
   uint32_t walk_min = 7;                  // restart kernel: a box phase ends once fewer lanes than this still walk (PTAMD_WALK_MIN; 4 / 5 / 7 / 8 / 10 / 12: 9331 / 9372 / 9405 / 9377 / 9338 / 9273 Msamples/s with the final shading code)
   bool pool_in_lds = true;                // restart kernel: pools of fresh paths in LDS when they fit (PTAMD_POOL_LDS=0: always the global slab)
+  bool pool_in_lds_wide = false;          // ... also for scenes walked from L2 (PTAMD_POOL_LDS_WIDE=1).  Off since round 4: the 36 KB the pools took are four more LDS
+                                          // entries of every lane's stack (7 -> 11: fewer pushes and pops through the global continuation, and the hand-scheduled visit
+                                          // needs room for four entries in EVERY lane's LDS part): atrium 1 590 -> 1 727 Msamples/s, tessellated indoor 3 849 -> 3 865
   uint32_t treelet_nodes = 512;           // wide walk: nodes of the top of the tree staged in LDS (PTAMD_TREELET; with LDS pools 341 / 512 / 640: 1286 / 1291 / 1275)
   uint32_t walk_min4 = 16;                // the same threshold for the four-wide walk (PTAMD_WALK_MIN4; 1/4/8/16/24: 813/902/960/994/971 Msamples/s)
   bool short_rcp = true;                  // restart kernel: 7-instruction exact 1/det where the scene allows it (PTAMD_SHORT_RCP=0: always the full division)
@@ -506,7 +511,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats, bool lat
       // the top of the tree (breadth-first numbering: nodes 0..340 are its first five levels when full) goes to LDS too:
       // 512 nodes = 64 KB of the one workgroup's 160 KB, then 7 stack entries per lane
       // ... and the waves' pools of fresh paths (PT_POOL_LDS_BYTES each), behind the stacks
-      const uint32_t pools = ctx->pool_in_lds ? waves * PT_POOL_LDS_BYTES : 0u;
+      const uint32_t pools = (ctx->pool_in_lds && ctx->pool_in_lds_wide) ? waves * PT_POOL_LDS_BYTES : 0u;
       // (the same LDS bytes hold twice as many 64-byte nodes)
       // chunk-major treelet (pt_kernels.hip: PT_TREELET_SOA): a region of fixed size whatever the number of nodes staged
       const uint32_t region = restart_treelet_region_bytes();
@@ -787,6 +792,7 @@ int ptamd_create(int32_t device_ordinal, ptamd_context** out)
   if (const char* e = tuning_env("PTAMD_WIDE8")) ctx->wide8 = std::atoi(e) != 0; // tuning knob
   if (const char* e = tuning_env("PTAMD_WIDE4Q")) ctx->wide4q = std::atoi(e) != 0; // tuning knob
   if (const char* e = tuning_env("PTAMD_POOL_LDS")) ctx->pool_in_lds = std::atoi(e) != 0; // tuning knob
+  if (const char* e = tuning_env("PTAMD_POOL_LDS_WIDE")) ctx->pool_in_lds_wide = std::atoi(e) != 0; // tuning knob
   if (const char* e = tuning_env("PTAMD_TREELET")) { // tuning knob
     int v = std::atoi(e);
     ctx->treelet_nodes = (uint32_t)(v < 0 ? 0 : (v > 1024 ? 1024 : v));
@@ -823,6 +829,7 @@ void ptamd_destroy(ptamd_context* ctx)
   for (auto& c : ctx->sample_scratch) free_scratch(c);
   for (hipStream_t is : ctx->internal) if (is) (void)hipStreamDestroy(is);
   (void)hipFree(ctx->d_timeline);
+  (void)hipFree(ctx->d_trace_spill);
   delete ctx;
 }
 
@@ -1159,6 +1166,58 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
   (void)hipFree(d_rays);
   (void)hipFree(d_out);
   return rc;
+}
+
+int ptamd_trace_rays_queue(ptamd_context* ctx, uint32_t scene_id, const float* rays_dev, uint32_t n, int32_t* out_dev, uint32_t config,
+                           uint32_t refill_min, void* stream, uint32_t* out_waves_per_cu)
+{
+  if (!ctx || scene_id >= ctx->scenes.size() || (n && (!rays_dev || !out_dev)) || config > 3u) { set_error("ptamd_trace_rays_queue: bad argument"); return PTAMD_ERR_ARG; }
+  if (n == 0) return PTAMD_OK;
+  PT_HIP(hipSetDevice(ctx->device));
+  const DeviceScene& s = ctx->scenes[scene_id];
+  if (s.n_nodes4 == 0) { set_error("ptamd_trace_rays_queue: the scene has no wide tree"); return PTAMD_ERR_ARG; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KParams p;
+  std::memset(&p, 0, sizeof p);
+  p.nodes4 = s.nodes4; p.n_nodes4 = s.n_nodes4; p.tris_bvh = s.tris_bvh; p.n_bvh_tris = s.n_bvh_tris;
+  p.lights = s.lights; p.n_lights = s.n_lights;
+  p.refill_min = refill_min < 1u ? 1u : (refill_min > 64u ? 64u : refill_min);
+  p.walk_min4 = ctx->walk_min4;
+  uint32_t threads, plane, bpc;
+  trace_queue_shape(config, &threads, &plane, &bpc);
+  const uint32_t waves = threads / 64u;
+  p.treelet_nodes = plane < s.n_nodes4 ? plane : s.n_nodes4;
+  const uint32_t need = 3u * s.depth4 + 1u;
+  const uint32_t share = 160u * 1024u / bpc - 512u;
+  const uint32_t treelet_bytes = plane * 128u;
+  uint32_t fit = (share - treelet_bytes) / (waves * 512u);
+  uint32_t cap = 7u;        // (what the restart kernel's waves get next to their pools: the same stack traffic in every configuration)
+  if (const char* ev = tuning_env("PTAMD_TRACE_STACK")) { int v = std::atoi(ev); if (v >= 1) cap = (uint32_t)v; }   // tuning knob
+  if (fit > cap) fit = cap;
+  p.stack_lds_entries = need < fit ? need : fit;
+  p.stack_spill_entries = need - p.stack_lds_entries;
+  const size_t lds = (size_t)treelet_bytes + (size_t)p.stack_lds_entries * waves * 512u;
+  const uint32_t n_blocks = (uint32_t)ctx->n_cus * bpc;
+  const size_t spill = (size_t)n_blocks * waves * p.stack_spill_entries * 512u + 16u;
+  if (spill > ctx->trace_spill_bytes) {
+    PT_HIP(hipDeviceSynchronize());
+    (void)hipFree(ctx->d_trace_spill);
+    ctx->d_trace_spill = nullptr; ctx->trace_spill_bytes = 0;
+    PT_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_trace_spill), spill));
+    ctx->trace_spill_bytes = spill;
+  }
+  p.stack_spill = ctx->d_trace_spill;
+  uint32_t* head = reinterpret_cast<uint32_t*>(ctx->d_stats + 28);
+  PT_HIP(hipMemsetAsync(head, 0, sizeof(uint32_t), st));
+  // (the occupancy query costs the host a millisecond: once per configuration and LDS size)
+  static thread_local struct { uint32_t config = ~0u; size_t lds = 0; int resident = 0; } cache;
+  const bool cached = cache.config == config && cache.lds == lds;
+  int resident = cache.resident;
+  hipError_t e = launch_trace_queue(p, config, lds, n_blocks, rays_dev, n, reinterpret_cast<int4*>(out_dev), head, cached ? nullptr : &resident, st);
+  if (e != hipSuccess) return hip_fail("ptamd_trace_rays_queue", e);
+  cache.config = config; cache.lds = lds; cache.resident = resident;
+  if (out_waves_per_cu) *out_waves_per_cu = (uint32_t)(resident < (int)bpc ? resident : (int)bpc) * waves;
+  return PTAMD_OK;
 }
 
 int ptamd_device_alloc(ptamd_context* ctx, size_t bytes, void** out)

@@ -152,6 +152,8 @@ SIGNATURES = {
                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "ptamd_host_bvh8_trace": (C.c_int, [C.POINTER(Face), C.c_uint32, C.POINTER(C.c_float), C.c_uint32,
                                        C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "ptamd_trace_rays_queue": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                        C.POINTER(C.c_uint32)]),
     "ptamd_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "ptamd_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ptamd_device_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),

@@ -141,6 +141,14 @@ class Context:
     def raytrace_ex(self, launch: N.Launch) -> None:
         N.check(self._lib.ptamd_raytrace_ex(self._h, C.byref(launch)))
 
+    def trace_rays_queue(self, scene_id: int, rays, out, config: int = 0, refill_min: int = 8, stream=None) -> int:
+        """The walk-only kernel fed from a ray queue (ptamd_trace_rays_queue): rays float32[n, 6] and out int32[n, 4] are device
+        tensors; asynchronous on `stream`.  Returns the waves resident per CU."""
+        waves = C.c_uint32(0)
+        N.check(self._lib.ptamd_trace_rays_queue(self._h, scene_id, _ptr(rays), int(rays.shape[0]), _ptr(out), config, refill_min,
+                                                 _stream_handle(stream), C.byref(waves)))
+        return int(waves.value)
+
     def release_captured(self, stream=None) -> None:
         """The graphs captured on `stream` are gone: its sample slab and ring slots are no longer pinned (ptamd_release_captured)."""
         N.check(self._lib.ptamd_release_captured(self._h, _stream_handle(stream)))

@@ -367,6 +367,15 @@ int ptamd_gamma_table_selftest(ptamd_context* ctx, uint64_t* out_checked, uint64
 int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel,
                      const float* rays_host, uint32_t n, int32_t* out_host);
 
+/* Measurement hook (round 4): the four-wide walk WITHOUT a path around it.  Persistent waves pull rays {dir.xyz, origin.xyz} from a
+ * queue in device memory and write {kind, index, t bits, 0} records (as ptamd_trace_rays with PTAMD_KERNEL_BVH_RESTART), a lane
+ * taking its next ray as soon as `refill_min` lanes of its wave are idle.  No path state in registers, so the same walk runs at
+ * config 0: 16 waves per CU (4 per SIMD), 512-node LDS treelet; 1: 20 waves (5 per SIMD), two workgroups with 256 nodes each;
+ * 2: 24 waves (6 per SIMD), 256 nodes each; 3: 16 waves, 256 nodes.  Asynchronous on `stream`; rays_dev / out_dev are device
+ * pointers; *out_waves_per_cu = waves resident per CU (occupancy query).  scripts/gpu_trace_queue.py, profiles/r04_notes.md. */
+int ptamd_trace_rays_queue(ptamd_context* ctx, uint32_t scene_id, const float* rays_dev, uint32_t n, int32_t* out_dev, uint32_t config,
+                           uint32_t refill_min, void* stream, uint32_t* out_waves_per_cu);
+
 /* Host mirror of the device BVH walk (same node/triangle records, same float operations),
  * so the builder's "equals brute force" contract can be tested without a GPU.  This is a
  * test hook for the acceleration structure only; it renders nothing.
