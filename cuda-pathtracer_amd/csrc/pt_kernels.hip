@@ -667,7 +667,14 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
   Hit inter;
   inter.normal = mk3(0.f); inter.diffuse_col = mk3(0.f);
   inter.dist = 0.f; inter.specular_col = st.specular_col; inter.ior = 0.f; inter.light = -1; inter.emission = 0.f;
+  long long ts0 = 0;
+  if (STATS) ts0 = clock64();
   const bool found = resolve_hit<STATS>(p, st.d, nearest, inter, cnt);
+  if (STATS) {   // [8]: the shading record (and texels) of the hit: fetch and decode
+    asm volatile("" : "+v"(inter.normal.x), "+v"(inter.diffuse_col.x), "+v"(inter.specular_col));
+    const long long ts1 = clock64();
+    if (PT_WAVE_ONE()) cnt.cyc[8] += (unsigned long long)(ts1 - ts0);
+  }
 
   if (!p.is_static) {
     st.acc = found ? inter.diffuse_col : env_lookup(p, st.d);
@@ -2063,16 +2070,21 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
       if (node == PT_END) {
         // the iteration's first variate (raytrace.cu:70) is drawn here, after the search: intersect() draws nothing, so the
         // path's random stream is the same, and r1 need not live (in scratch, as it turned out) across the walk
+        long long tl0 = 0;
+        if (STATS) tl0 = clock64();
         const float r1 = path_pre(p, st);
         Nearest n;
         n.t = best.t; n.u = best.u; n.v = best.v; n.idx = best.idx;
         n = nearest_lights(p, st.o, st.d, n);
         walking = false;
+        long long tl1 = 0;
+        if (STATS) { asm volatile("" : "+v"(n.t), "+v"(n.idx)); tl1 = clock64(); if (PT_WAVE_ONE()) cnt.cyc[3] += (unsigned long long)(tl1 - tl0); }   // [3]: r1 + light loop
         if (path_post<STATS>(p, st, r1, n, cnt)) {
           path_finish_sample(p, st);
           idle = true;
           if (STATS) samples++;
         }
+        if (STATS) { const long long tl2 = clock64(); if (PT_WAVE_ONE()) cnt.cyc[9] += (unsigned long long)(tl2 - tl1); }   // [9]: path_post (record fetch [8] included) + parked sample
       }
     }
     if (STATS) {   // (outside the divergent part: every lane of the wave is here)

@@ -328,8 +328,8 @@ int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_t
 
 /* Where the waves of the last ptamd_raytrace_stats launch of PTAMD_KERNEL_BVH_RESTART spent their shader-clock cycles, summed
  * over the waves (instrumented build only): out[0] pool refill (tickets, path_begin), [1] box phases of the wide walk, [2] its
- * leaf phases, [3] unused (light loop + shading = [4] - [0] - [1] - [2]), [4] the whole round loop, [5] leaf phases entered, [6] node fetches of the four-wide walk (issue to data), [7] its visits as a whole
- * (fetch, box tests, pushes, pops), [8], [9] unused.  Synchronises. */
+ * leaf phases, [3] r1 + light loop (light loop + shading + bookkeeping = [4] - [0] - [1] - [2]), [4] the whole round loop, [5] leaf phases entered, [6] node fetches of the four-wide walk (issue to data), [7] its visits as a whole
+ * (fetch, box tests, pushes, pops), [8] shading record fetch and decode, [9] path_post ([8] included) + parking the sample.  Synchronises. */
 int ptamd_phase_cycles(ptamd_context* ctx, uint64_t out[10]);
 
 /* Where a launch's time goes (measurement hook of the default kernel; profiles/r03_tail_*).  After ptamd_set_timeline(ctx, n)

@@ -53,6 +53,9 @@ with tempfile.TemporaryDirectory(prefix="ptamd_atrium_") as d:
             "cycles_per_visit_fetch_tests_pushes_pops": cyc["visits"] / max(s["wave_node_iters"], 1),
             "cycles_per_leaf_phase": cyc["leaf_phases"] / max(cyc["leaf_phases_entered"], 1),
             "cycles_per_round_of_shading": cyc["lights_and_shading"] / max(s["fetch_events"], 1),
+            "cycles_per_round": {"r1_and_light_loop": cyc["light_loop"] / max(s["fetch_events"], 1),
+                                 "shading_record_fetch": cyc["shading_record_fetch"] / max(s["fetch_events"], 1),
+                                 "path_post_incl_fetch_and_parking": cyc["path_post_and_parking"] / max(s["fetch_events"], 1)},
             "build_id": P.native.load().ptamd_build_id().decode(),
         })
         print(json.dumps(out))
