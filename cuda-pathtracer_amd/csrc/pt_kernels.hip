@@ -386,8 +386,9 @@ PT_DEV int texture_idx(const TexDesc& tex, float uvx, float uvy)
 
 struct Counters { uint32_t rays, nodes, tris, mesh_hits, nmap_hits, wave_node_iters, wave_tri_iters, fetch_events, fetch_rays, idle3[3];
                   // instrumented restart kernel: shader-clock cycles of a wave by phase — 0 pool refill, 1 box phases, 2 leaf phases, 3 light loop + shading,
-                  // 4 the whole round loop; 5 leaf phases entered (added by one lane per wave: sums over waves)
-                  unsigned long long cyc[10]; };   // [6] node fetch (issue -> data), [7] box tests + pushes, [8] pops after a visit without a hit (instrumented four-wide float walk)
+                  // 4 the whole round loop; 5 leaf phases entered; 8 shading record fetch; 9 path_post + parking; 10 path_post up to the BSDF sample; 11 the BSDF sample
+                  // (added by one lane per wave: sums over waves)
+                  unsigned long long cyc[16]; };   // [6] node fetch (issue -> data), [7] box tests + pushes, [8] pops after a visit without a hit (instrumented four-wide float walk)
 // one lane per executing wave adds a wave-level measurement
 #define PT_WAVE_ONE() ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1))
 
@@ -700,6 +701,8 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
     }
   }
 
+  long long tp0 = 0;
+  if (STATS) { tp0 = clock64(); if (PT_WAVE_ONE()) cnt.cyc[10] += (unsigned long long)(tp0 - ts0); }   // [10]: up to here (fetch + the misses' loop)
   const f3 d = st.d;
   const float cos_theta = dot(inter.normal, d);
   f3 oriented_normal = inter.normal;
@@ -755,6 +758,7 @@ PT_DEV bool path_post(const KParams& p, Path& st, float r1, Nearest nearest, Cou
       }
     }
   }
+  if (STATS) { asm volatile("" : "+v"(st.d.x), "+v"(st.o.x), "+v"(st.throughput.x)); const long long tp1 = clock64(); if (PT_WAVE_ONE()) cnt.cyc[11] += (unsigned long long)(tp1 - tp0); }   // [11]: the BSDF sample
   const float pmax = __builtin_fmaxf(st.throughput.x, __builtin_fmaxf(st.throughput.y, st.throughput.z));
   if (r1 > pmax && st.b() > 1u) return true;
   st.throughput = st.throughput * rcp_hot(pmax);
@@ -890,7 +894,7 @@ PT_DEV void flush_counters(const KParams& p, const Counters& cnt, uint32_t sampl
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && s) atomicAdd(&p.stats[k], s);
   }
-  for (int k = 0; k < 10; ++k) {
+  for (int k = 0; k < 16; ++k) {
     unsigned long long s = cnt.cyc[k];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && s) atomicAdd(&p.stats[16 + k], s);

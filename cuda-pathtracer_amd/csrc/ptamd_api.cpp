@@ -1035,7 +1035,7 @@ int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_t
   PT_HIP(hipSetDevice(ctx->device));
   hipStream_t st = launch ? static_cast<hipStream_t>(launch->stream) : nullptr;
   PT_HIP(hipMemsetAsync(ctx->d_stats, 0, 13 * sizeof(unsigned long long), st));
-  PT_HIP(hipMemsetAsync(ctx->d_stats + 16, 0, 10 * sizeof(unsigned long long), st));
+  PT_HIP(hipMemsetAsync(ctx->d_stats + 16, 0, 12 * sizeof(unsigned long long), st));
   int rc = do_launch(ctx, launch, true);
   if (rc != PTAMD_OK) return rc;
   PT_HIP(hipStreamSynchronize(st));
@@ -1049,12 +1049,12 @@ int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_t
   return PTAMD_OK;
 }
 
-int ptamd_phase_cycles(ptamd_context* ctx, uint64_t out[10])
+int ptamd_phase_cycles(ptamd_context* ctx, uint64_t out[12])
 {
   if (!ctx || !out) { set_error("ptamd_phase_cycles: null argument"); return PTAMD_ERR_ARG; }
   PT_HIP(hipSetDevice(ctx->device));
   PT_HIP(hipDeviceSynchronize());
-  PT_HIP(hipMemcpy(out, ctx->d_stats + 16, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  PT_HIP(hipMemcpy(out, ctx->d_stats + 16, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return PTAMD_OK;
 }
 

@@ -160,9 +160,9 @@ class Context:
 
     def phase_cycles(self) -> dict:
         """Shader-clock cycles by phase, summed over the waves of the last raytrace_stats launch of the restart kernel."""
-        v = (C.c_uint64 * 10)()
+        v = (C.c_uint64 * 12)()
         N.check(self._lib.ptamd_phase_cycles(self._h, v))
-        d = dict(zip(("refill", "box_phases", "leaf_phases", "light_loop", "round_loop", "leaf_phases_entered", "node_fetches", "visits", "shading_record_fetch", "path_post_and_parking"), [int(x) for x in v]))
+        d = dict(zip(("refill", "box_phases", "leaf_phases", "light_loop", "round_loop", "leaf_phases_entered", "node_fetches", "visits", "shading_record_fetch", "path_post_and_parking", "path_post_to_bsdf", "bsdf_sample"), [int(x) for x in v]))
         d["lights_and_shading"] = d["round_loop"] - d["refill"] - d["box_phases"] - d["leaf_phases"]   # (what the three stamps leave: light loop + path_post + round bookkeeping)
         return d
 

@@ -329,8 +329,9 @@ int ptamd_raytrace_stats(ptamd_context* ctx, const ptamd_launch* launch, ptamd_t
 /* Where the waves of the last ptamd_raytrace_stats launch of PTAMD_KERNEL_BVH_RESTART spent their shader-clock cycles, summed
  * over the waves (instrumented build only): out[0] pool refill (tickets, path_begin), [1] box phases of the wide walk, [2] its
  * leaf phases, [3] r1 + light loop (light loop + shading + bookkeeping = [4] - [0] - [1] - [2]), [4] the whole round loop, [5] leaf phases entered, [6] node fetches of the four-wide walk (issue to data), [7] its visits as a whole
- * (fetch, box tests, pushes, pops), [8] shading record fetch and decode, [9] path_post ([8] included) + parking the sample.  Synchronises. */
-int ptamd_phase_cycles(ptamd_context* ctx, uint64_t out[10]);
+ * (fetch, box tests, pushes, pops), [8] shading record fetch and decode, [9] path_post ([8] included) + parking the sample, [10] path_post up to the BSDF sample ([8] + the misses' loop), [11] the BSDF sample.
+ * Synchronises. */
+int ptamd_phase_cycles(ptamd_context* ctx, uint64_t out[12]);
 
 /* Where a launch's time goes (measurement hook of the default kernel; profiles/r03_tail_*).  After ptamd_set_timeline(ctx, n)
  * every launch of PTAMD_KERNEL_BVH_RESTART with at most n waves in its grid records four device time stamps per wave

@@ -55,7 +55,9 @@ with tempfile.TemporaryDirectory(prefix="ptamd_atrium_") as d:
             "cycles_per_round_of_shading": cyc["lights_and_shading"] / max(s["fetch_events"], 1),
             "cycles_per_round": {"r1_and_light_loop": cyc["light_loop"] / max(s["fetch_events"], 1),
                                  "shading_record_fetch": cyc["shading_record_fetch"] / max(s["fetch_events"], 1),
-                                 "path_post_incl_fetch_and_parking": cyc["path_post_and_parking"] / max(s["fetch_events"], 1)},
+                                 "path_post_incl_fetch_and_parking": cyc["path_post_and_parking"] / max(s["fetch_events"], 1),
+                                 "path_post_up_to_the_bsdf_sample": cyc["path_post_to_bsdf"] / max(s["fetch_events"], 1),
+                                 "bsdf_sample": cyc["bsdf_sample"] / max(s["fetch_events"], 1)},
             "build_id": P.native.load().ptamd_build_id().decode(),
         })
         print(json.dumps(out))
