@@ -1106,3 +1106,67 @@ def test_long_batches_are_issued_four_frames_at_a_time(P, gpu_ctx, indoor):
     b.render(spp=13, bounces=4, batched=False, reset=True)
     torch.cuda.synchronize()
     assert_same(a.accum.cpu().numpy(), a.surface.cpu().numpy(), b.accum.cpu().numpy(), b.surface.cpu().numpy(), "13 frames: batched vs one launch per frame")
+
+
+def test_round4_scheduling_knobs_change_no_bit(P, O, monkeypatch, indoor):
+    """Scheduling paths of round 4 that the default configuration does not take: XCD-local tile regions (PTAMD_XCD_REGIONS: ticket ->
+    tile through a 4 x 2 grid of the frame, frames of a tile side by side; measured slower, kept behind the knob) on an LDS-resident
+    and on a wide-walk scene, ragged frame sizes and interleaved bands included; the wide walk with its pools of fresh paths back in
+    LDS (PTAMD_POOL_LDS_WIDE=1: seven stack entries per lane instead of eleven).  A path's arithmetic never depends on where or
+    when it runs: every frame must equal the oracle's."""
+    import torch
+    monkeypatch.setenv("PTAMD_TUNING", "1")
+    rng = np.random.default_rng(91)
+    big = make_scene(P, random_soup(rng, 2500, extent=2.5, size=0.3), lights=[((0.0, 3.0, 1.0), (1, 1, 1), 6.0, 0.7)])
+    cube_big = synthetic_cubemap(rng, 4)
+    cube = P.cubemap_for_scene(indoor)
+    ref_big = O.render(O.OracleScene.from_host_scene(big, cube_big), O.camera_from_record(big.camera), 136, 72, spp=3, bounces=4)
+    ref_in = {}
+    for (w, h) in ((130, 47), (264, 136)):
+        ref_in[(w, h)] = O.render(O.OracleScene.from_host_scene(indoor, cube), O.camera_from_record(indoor.camera), w, h, spp=3, bounces=3)
+    for knobs in ({"PTAMD_XCD_REGIONS": "2"}, {"PTAMD_XCD_REGIONS": "1", "PTAMD_POOL_LDS_WIDE": "1"}, {"PTAMD_POOL_LDS_WIDE": "1", "PTAMD_STACK_LDS": "3"}):
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        with P.Context(0) as ctx:
+            ids = (ctx.upload_scene(big), ctx.upload_cubemap(cube_big))
+            for batched in (False, True):
+                fr = P.FrameRenderer(ctx, *ids, big.camera_struct(), 136, 72)
+                fr.render(spp=3, bounces=4, kernel=P.KERNEL_BVH_RESTART, batched=batched)
+                torch.cuda.synchronize()
+                assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref_big, f"wide walk, {knobs}, batched={batched}")
+            ids = (ctx.upload_scene(indoor), ctx.upload_cubemap(cube))
+            for (w, h), ref in ref_in.items():
+                fr = P.FrameRenderer(ctx, *ids, indoor.camera_struct(), w, h)
+                fr.render(spp=3, bounces=3, kernel=P.KERNEL_BVH_RESTART, batched=True)
+                torch.cuda.synchronize()
+                assert_same(fr.accum.cpu().numpy(), fr.surface.cpu().numpy(), *ref, f"indoor {w}x{h}, {knobs}")
+            # interleaved bands of a two-rank split: rank 1's bands of 8 rows equal the same rows of the full frame
+            w, h = 264, 136
+            fr = P.FrameRenderer(ctx, *ids, indoor.camera_struct(), w, h, interleave=(2, 1, 8))
+            fr.render(spp=3, bounces=3, kernel=P.KERNEL_BVH_RESTART, batched=True)
+            torch.cuda.synchronize()
+            rows = np.concatenate([np.arange(b, e) for b, e in P.interleaved_bands(h, 2, 1, 8)])
+            np.testing.assert_array_equal(fr.surface.cpu().numpy(), ref_in[(w, h)][1][rows], err_msg=f"interleaved bands, {knobs}")
+        for k in knobs:
+            monkeypatch.delenv(k)
+
+
+def test_walk_only_queue_kernel_equals_the_brute_force_oracle(P, O, gpu_ctx):
+    """ptamd_trace_rays_queue (the four-wide walk fed from a ray queue, a measurement hook: scripts/gpu_trace_queue.py): its records
+    equal the brute-force oracle's in every configuration (16 / 20 / 24 waves per CU, treelet sizes) and refill threshold, also when
+    the queue is shorter than one wave or than the grid."""
+    import torch
+    rng = np.random.default_rng(123)
+    soup = make_scene(P, random_soup(rng, 3000, extent=3.0, size=0.25), lights=[((0.0, 1.0, 0.5), (1, 1, 1), 3.0, 0.4)])
+    sid = gpu_ctx.upload_scene(soup)
+    osc = O.OracleScene.from_host_scene(soup, P.cubemap_from_color())
+    for n in (1, 63, 4097, 30000):
+        rays = random_rays(rng, n)
+        want = O.intersect(osc, rays)
+        r = torch.from_numpy(rays).cuda()
+        for config in (0, 1, 2, 3):
+            for refill in (1, 8, 64):
+                out = torch.full((n, 4), -7, dtype=torch.int32, device="cuda")
+                gpu_ctx.trace_rays_queue(sid, r, out, config, refill)
+                torch.cuda.synchronize()
+                np.testing.assert_array_equal(out.cpu().numpy(), want, err_msg=f"n={n} config={config} refill={refill}")
