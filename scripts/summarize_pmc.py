@@ -51,7 +51,7 @@ batched = (not bargs.sequential) and kernel in ("persistent", "split", "restart"
 fpl = min(bargs.spp, 4) if batched else 1   # (ptamd_api.cpp: kMaxFramesPerSlab — longer batches are issued four frames per launch)
 samples = bargs.width * bargs.height * fpl
 d = {"samples_per_launch": samples}
-if res.get("SQ_ACTIVE_INST_VALU"):
+if res.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in res:
     d["valu_active_lanes_per_inst(of 64)"] = res["SQ_THREAD_CYCLES_VALU"] / res["SQ_ACTIVE_INST_VALU"]
 if res.get("SQ_BUSY_CYCLES"):
     d["mean_waves_resident(SQ_WAVE_CYCLES/SQ_BUSY_CYCLES)"] = res["SQ_WAVE_CYCLES"] / res["SQ_BUSY_CYCLES"]

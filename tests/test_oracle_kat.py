@@ -6,6 +6,7 @@ reference source states (file:line in each test).  Parity with the CUDA binary s
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -269,3 +270,61 @@ def test_cubemap_face_selection_and_filter(O, P):
     lib.or_tex_cubemap(C.byref(sc.c), 0.3, -0.2, 0.9, out)
     assert [out[0], out[1], out[2], out[3]] == [np.float32(19) / np.float32(255), np.float32(27) / np.float32(255),
                                                  np.float32(35) / np.float32(255), 0.0]
+
+
+ROCRAND_PROBE = r"""
+// Prints outputs of rocRAND's XORWOW engine (an independent implementation in the ROCm image, host-callable) for given seeds.
+#include <rocrand/rocrand_xorwow.h>
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char** argv)
+{
+  for (int a = 1; a < argc; ++a) {
+    rocrand_device::xorwow_engine e(std::strtoull(argv[a], nullptr, 0), 0, 0);
+    for (int i = 0; i < 64; ++i) std::printf("%u%c", e.next(), i == 63 ? '\n' : ' ');
+  }
+  return 0;
+}
+"""
+
+
+def test_xorwow_step_and_state_layout_equal_rocrand(O, tmp_path_factory):
+    """Third-party pin of SURVEY §8-a13's generator: rocRAND ships the same Marsaglia xorwow (five xorshift words + Weyl word, the
+    same base state 123456789 / 362436069 / 521288629 / 88675123 / 5783321 / 6615241, the same way the two scrambled seed words
+    t0 / t1 enter the state) with its OWN scramble constants (rocrand_xorwow.h:113-116 — "arbitrary prime numbers"; cuRAND's are
+    0xaad26b49 / 0xf7dcefdd and 1099087573 / 2591861531, which no file in this image holds: that part stays as published).
+    The oracle's step, started from the state rocRAND's seeding gives, must produce rocRAND's outputs: the step function, the
+    word order of the state and the output sum are then pinned by code that is not the builder's."""
+    import shutil
+    import subprocess
+    hdr = "/opt/rocm/include/rocrand/rocrand_xorwow.h"
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not (os.path.exists(hdr) and os.path.exists(hipcc)):
+        pytest.skip("rocRAND headers / hipcc not in this image")
+    d = tmp_path_factory.mktemp("rocrand_probe")
+    src = d / "probe.cpp"
+    src.write_text(ROCRAND_PROBE)
+    exe = d / "probe"
+    r = subprocess.run([hipcc, "-O1", "-o", str(exe), str(src)], capture_output=True, text=True)   # host code only: no GPU needed
+    if r.returncode != 0:
+        pytest.skip("rocRAND probe does not build here: " + r.stderr[-300:])
+    seeds = [0, 1, 0xC0A9496A, 0xFFFFFFFF, 987654321, 0x123456789ABCDEF]
+    out = subprocess.run([str(exe)] + [str(s) for s in seeds], capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    lib = O.load()
+    m = 0xFFFFFFFF
+    for seed, line in zip(seeds, out):
+        want = [int(x) for x in line.split()]
+        s0 = (seed & m) ^ 0x2C7F967F                    # rocrand_xorwow.h:113-116
+        s1 = ((seed >> 32) & m) ^ 0xA03697CB
+        t0 = (1228688033 * s0) & m
+        t1 = (2073658381 * s1) & m
+        st = (C.c_uint32 * 6)((123456789 + t0) & m, 362436069 ^ t0, (521288629 + t1) & m, 88675123 ^ t1, (5783321 + t0) & m,
+                              (6615241 + t1 + t0) & m)
+        got = [lib.or_xorwow_next(st) for _ in range(64)]
+        assert got == want, f"seed {seed:#x}"
+    # and the oracle's own seeding has exactly that shape with cuRAND's constants
+    st = (C.c_uint32 * 6)()
+    lib.or_xorwow_init(0x1234, st)
+    s0, s1 = 0x1234 ^ 0xAAD26B49, 0xF7DCEFDD
+    t0, t1 = (1099087573 * s0) & m, (2591861531 * s1) & m
+    assert list(st) == [(123456789 + t0) & m, 362436069 ^ t0, (521288629 + t1) & m, 88675123 ^ t1, (5783321 + t0) & m, (6615241 + t1 + t0) & m]
