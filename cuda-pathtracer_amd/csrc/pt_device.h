@@ -299,6 +299,7 @@ struct KParams {
   float4* pool;
   uint32_t pool_lds_offset;   // != 0: the pools live in LDS this many bytes behind the start of the dynamic LDS (2 304 bytes per wave)
   uint32_t round_min, round_div;
+  uint32_t round_div_m16;   // ceil(2^16 / round_div): x / round_div == (x * round_div_m16) >> 16 for x < 1024 (the waves divide lane counts: two scalar instructions instead of the fifteen of a 32-bit division)
   uint32_t walk_min;   // a box phase ends once fewer lanes than this are still walking (1: when none is)
   uint32_t small_det;  // != 0: the scene's coordinates are <= 1e8, so Moller-Trumbore determinants stay below 2^125
   // != 0: the environment is one colour (a 1x1 cubemap whose six texels are bit-identical — what the reference ends up

@@ -71,6 +71,15 @@ namespace ptamd {
 #ifndef PT_ASM_WALK
 #define PT_ASM_WALK 1
 #endif
+#ifndef PT_ASM_LEAF_WIDE
+#define PT_ASM_LEAF_WIDE 0
+#endif
+#ifndef PT_ASM_LEAF_EXITS
+#define PT_ASM_LEAF_EXITS 7
+#endif
+#ifndef PT_ASM_LEAF
+#define PT_ASM_LEAF 1 /* hand-scheduled Moller-Trumbore (mt_test_asm) in the leaf phases of the LDS-resident restart kernel */
+#endif
 #ifndef PT_WALK_PRIO
 #define PT_WALK_PRIO 3 /* s_setprio inside the hand-scheduled box loop: waves that walk win VALU arbitration (+0.7 %) */
 #endif
@@ -111,6 +120,116 @@ PT_DEV void mt_test(float4 a, float4 b, float4 c, f3 o, f3 d, Best& best, bool s
   if (ORDERED) take = t < best.t && t > 0.0f;
   else take = t > 0.0f && (t < best.t || (t == best.t && idx < best.idx && best.idx != PT_END));
   if (take) { best.t = t; best.u = u; best.v = v; best.idx = idx; }
+}
+
+// mt_test<false> for scenes with small determinants (rcp_exact_in_range), hand-scheduled: the same operations in the same order, but a
+// lane that fails a test leaves by clearing its EXEC bit with the comparison itself (v_cmpx) instead of through hipcc's
+// s_and_saveexec / s_cbranch_execz / s_or_b64 group per early exit and its s_and / s_or chains for the (t, index) rule: 2 scalar
+// instructions per triangle instead of ~30.  The CU's single scalar pipe issues half as many instructions per clock as its vector
+// pipes and the resident kernel keeps both ~58 % busy (scripts/ubench/ifetch_rate.hip, profiles/r04_notes.md).
+// NaN behaviour is the reference's: every rejection is written as the negation it is in intersection.cuh:110-128
+// (`det < eps`, `u < 0 || u > 1`, `v < 0 || u + v > 1` reject; an unordered comparison does not), `t > 0` accepts.
+// The (t, index) rule `t < best.t || (t == best.t && idx < best.idx && best.idx != PT_END)`: among lanes with t <= best.t,
+// idx + 1 < (t == best.t ? best.idx + 1 : 0xFFFFFFFF) as unsigned numbers (PT_END + 1 wraps to 0: no index is below it).
+PT_DEV void mt_test_asm(float4 a, float4 b, float2 c, f3 o, f3 d, Best& best)
+{
+  float px, py, pz, qx, qy, qz, det, inv, u, v, t0, t1;
+  float v0x = b.z, v0y = b.w, v0z = c.x;   // overwritten by t_vec
+  unsigned long long save;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      // p_vec = cross(d, e2)
+      "v_mul_f32 %[px], %[dy], %[e2z]\n\t"
+      "v_mul_f32 %[t0], %[dz], %[e2y]\n\t"
+      "v_mul_f32 %[py], %[dz], %[e2x]\n\t"
+      "v_mul_f32 %[t1], %[dx], %[e2z]\n\t"
+      "v_sub_f32 %[px], %[px], %[t0]\n\t"
+      "v_sub_f32 %[py], %[py], %[t1]\n\t"
+      "v_mul_f32 %[pz], %[dx], %[e2y]\n\t"
+      "v_mul_f32 %[t0], %[dy], %[e2x]\n\t"
+      "v_sub_f32 %[pz], %[pz], %[t0]\n\t"
+      // det = dot(e1, p_vec)
+      "v_mul_f32 %[t0], %[e1x], %[px]\n\t"
+      "v_mul_f32 %[t1], %[e1y], %[py]\n\t"
+      "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+      "v_mul_f32 %[t1], %[e1z], %[pz]\n\t"
+      "v_add_f32 %[det], %[t1], %[t0]\n\t"
+      "v_cmpx_ngt_f32 vcc, 0x33d6bf95, %[det]\n\t"       // keep !(1e-7f > det)
+#if PT_ASM_LEAF_EXITS & 1
+      "s_cbranch_execz 9f\n\t"
+#endif
+      // inv_det = rcp_exact_in_range(det); t_vec = o - v0 fills the wait state a transcendental's consumer needs
+      "v_rcp_f32 %[inv], %[det]\n\t"
+      "v_sub_f32 %[v0x], %[ox], %[v0x]\n\t"
+      "v_sub_f32 %[v0y], %[oy], %[v0y]\n\t"
+      "v_sub_f32 %[v0z], %[oz], %[v0z]\n\t"
+      "v_fma_f32 %[t0], -%[det], %[inv], 1.0\n\t"
+      "v_fma_f32 %[inv], %[t0], %[inv], %[inv]\n\t"
+      "v_fma_f32 %[t0], -%[det], %[inv], 1.0\n\t"
+      "v_fma_f32 %[t0], %[t0], %[inv], %[inv]\n\t"
+      "v_fma_f32 %[t1], -%[det], %[t0], 1.0\n\t"
+      "v_fma_f32 %[inv], %[t1], %[inv], %[t0]\n\t"
+      // u = dot(t_vec, p_vec) * inv_det
+      "v_mul_f32 %[t0], %[v0x], %[px]\n\t"
+      "v_mul_f32 %[t1], %[py], %[v0y]\n\t"
+      "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+      "v_mul_f32 %[t1], %[pz], %[v0z]\n\t"
+      "v_add_f32 %[t0], %[t1], %[t0]\n\t"
+      "v_mul_f32 %[u], %[t0], %[inv]\n\t"
+      "v_cmpx_ngt_f32 vcc, 0, %[u]\n\t"                  // keep !(u < 0)
+      "v_cmpx_nlt_f32 vcc, 1.0, %[u]\n\t"                // keep !(u > 1)
+#if PT_ASM_LEAF_EXITS & 2
+      "s_cbranch_execz 9f\n\t"
+#endif
+      // qvec = cross(t_vec, e1)
+      "v_mul_f32 %[qx], %[e1z], %[v0y]\n\t"
+      "v_mul_f32 %[t0], %[e1y], %[v0z]\n\t"
+      "v_mul_f32 %[qy], %[e1x], %[v0z]\n\t"
+      "v_mul_f32 %[t1], %[e1z], %[v0x]\n\t"
+      "v_sub_f32 %[qx], %[qx], %[t0]\n\t"
+      "v_sub_f32 %[qy], %[qy], %[t1]\n\t"
+      "v_mul_f32 %[qz], %[e1y], %[v0x]\n\t"
+      "v_mul_f32 %[t0], %[e1x], %[v0y]\n\t"
+      "v_sub_f32 %[qz], %[qz], %[t0]\n\t"
+      // v = dot(d, qvec) * inv_det
+      "v_mul_f32 %[t0], %[dx], %[qx]\n\t"
+      "v_mul_f32 %[t1], %[dy], %[qy]\n\t"
+      "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+      "v_mul_f32 %[t1], %[dz], %[qz]\n\t"
+      "v_add_f32 %[t0], %[t1], %[t0]\n\t"
+      "v_mul_f32 %[v], %[t0], %[inv]\n\t"
+      "v_cmpx_ngt_f32 vcc, 0, %[v]\n\t"                  // keep !(v < 0)
+      "v_add_f32 %[t0], %[u], %[v]\n\t"
+      "v_cmpx_nlt_f32 vcc, 1.0, %[t0]\n\t"               // keep !(u + v > 1)
+#if PT_ASM_LEAF_EXITS & 4
+      "s_cbranch_execz 9f\n\t"
+#endif
+      // t = dot(e2, qvec) * inv_det
+      "v_mul_f32 %[t0], %[e2x], %[qx]\n\t"
+      "v_mul_f32 %[t1], %[e2y], %[qy]\n\t"
+      "v_add_f32 %[t0], %[t0], %[t1]\n\t"
+      "v_mul_f32 %[t1], %[e2z], %[qz]\n\t"
+      "v_add_f32 %[t0], %[t1], %[t0]\n\t"
+      "v_mul_f32 %[det], %[t0], %[inv]\n\t"               // t (in det's register)
+      "v_cmpx_lt_f32 vcc, 0, %[det]\n\t"                  // keep t > 0
+      "v_cmpx_le_f32 vcc, %[det], %[bt]\n\t"              // keep t <= best.t
+      "v_cmp_eq_f32 vcc, %[det], %[bt]\n\t"
+      "v_add_u32 %[t0], 1, %[idx]\n\t"
+      "v_add_u32 %[t1], 1, %[bi]\n\t"
+      "v_cndmask_b32 %[t1], -1, %[t1], vcc\n\t"           // (two VALU since the compare: the wait states a VCC reader needs)
+      "v_cmpx_lt_u32 vcc, %[t0], %[t1]\n\t"
+      "v_mov_b32 %[bt], %[det]\n\t"
+      "v_mov_b32 %[bu], %[u]\n\t"
+      "v_mov_b32 %[bv], %[v]\n\t"
+      "v_mov_b32 %[bi], %[idx]\n\t"
+      "9:\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      : [bt] "+v"(best.t), [bu] "+v"(best.u), [bv] "+v"(best.v), [bi] "+v"(best.idx), [v0x] "+v"(v0x), [v0y] "+v"(v0y), [v0z] "+v"(v0z),
+        [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [qx] "=&v"(qx), [qy] "=&v"(qy), [qz] "=&v"(qz), [det] "=&v"(det), [inv] "=&v"(inv),
+        [u] "=&v"(u), [v] "=&v"(v), [t0] "=&v"(t0), [t1] "=&v"(t1), [save] "=&s"(save)
+      : [e1x] "v"(a.x), [e1y] "v"(a.y), [e1z] "v"(a.z), [e2x] "v"(a.w), [e2y] "v"(b.x), [e2z] "v"(b.y), [idx] "v"(f_as_u(c.y)),
+        [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [dx] "v"(d.x), [dy] "v"(d.y), [dz] "v"(d.z)
+      : "vcc");
 }
 
 // The reference algorithm: every face in storage order.  `tris` is LDS (or global); the
@@ -247,7 +366,7 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
   //   < 0x8000  LDS byte address of the box to test next          0xFFFF  end of the walk
   //   0x8000 | count << 11 | first   "park: test these triangle records" (only ever a hit code, of the leaf itself)
   // so one v_cndmask with sub-dword selects yields the next state and one unsigned compare says whether to keep
-  // walking: 16 VALU, 4 SALU and 8 LDS cycles per iteration (the plain layout took 33 / 20 / 10; lo / hi boxes 20 VALU).  A lane that parks
+  // walking: 16 VALU, 3 SALU and 8 LDS cycles per iteration (the plain layout took 33 / 20 / 10; lo / hi boxes 20 VALU).  A lane that parks
   // stops executing: the link word it read last is its leaf's, whose upper half says where the walk goes on after the tests.
   unsigned long long save;
   uint32_t link_word; // the link word a lane read last (a lane that parks read its leaf's)
@@ -287,8 +406,10 @@ PT_DEV void walk_to_leaf_lds_state(uint32_t& state, uint32_t lnk, const Walk& w,
       "s_waitcnt lgkmcnt(0)\n\t"
       "s_nop 0\n\t"                                    // a VALU read of VCC needs 2 wait states after the VALU compare that wrote it
       "v_cndmask_b32_sdwa %[st], %[lw], %[lw], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
-      "v_cmp_gt_u32 vcc, 0x8000, %[st]\n\t"            // a node address: keep walking (else parked at a leaf, or done)
-      "s_and_b64 exec, exec, vcc\n\t"
+      // a node address: keep walking (else parked at a leaf, or done).  The compare writes EXEC itself: one scalar instruction less per
+      // iteration than v_cmp + s_and_b64 — the CU's one scalar pipe issues half as many instructions per clock as its four vector pipes
+      // (scripts/ubench/ifetch_rate.hip) and this kernel keeps both ~58 % busy: +0.7 % on the headline
+      "v_cmpx_gt_u32 vcc, 0x8000, %[st]\n\t"
       "s_bcnt1_i32_b64 %[walkers], exec\n\t"
       "s_cmp_ge_u32 %[walkers], %[wmin]\n\t"
       "s_cbranch_scc1 1b\n\t"
@@ -323,10 +444,19 @@ PT_DEV void walk_to_leaf_lds(uint32_t lds_nodes, Walk& w, uint32_t& leaf_first, 
   w.node = walk_lds_node(lds_nodes, state);
 }
 
-template <bool STATS>
+template <bool STATS, bool ASM = false>
 PT_DEV void walk_leaf(const float4* tris, Walk& w, uint32_t leaf_first, uint32_t leaf_count, uint32_t& n_tris,
                       uint32_t& wave_tri_iters, bool small_det = false, uint32_t stride = 3u /* float4 per triangle record */)
 {
+  if (ASM && !STATS && PT_ASM_LEAF && small_det) {   // (small_det is wave-uniform: one scalar branch per leaf phase)
+    for (uint32_t k = 0; k < leaf_count; ++k) {
+      const float4* r = tris + (leaf_first + k) * stride;
+      const float4 a = r[0], b = r[1];
+      const float2 c = *reinterpret_cast<const float2*>(r + 2);
+      mt_test_asm(a, b, c, w.o, w.d, w.best);
+    }
+    return;
+  }
   for (uint32_t k = 0; k < leaf_count; ++k) {
     if (STATS) {
       const unsigned long long act = __ballot(1);
@@ -1162,14 +1292,14 @@ PT_DEV void pool_load(const float4* slab, uint32_t e, Path& st)
 // once fewer than min(round_min, entering lanes / round_div) are unfinished.  node == PT_END on return: finished.
 template <bool STATS, bool NODES_IN_LDS>
 PT_DEV void traverse_round(const float4* nodes, const float4* tris, uint32_t n_nodes, f3 o, f3 d, Best& best, uint32_t& node,
-                           uint32_t round_min, uint32_t round_div, uint32_t walk_min, bool small_det, Counters& cnt)
+                           uint32_t round_min, uint32_t round_div, uint32_t round_div_m16, uint32_t walk_min, bool small_det, Counters& cnt)
 {
   Walk w;
   walk_init(w, o, d, n_nodes, NODES_IN_LDS && !STATS && PT_ASM_WALK);
   w.best = best;
   w.node = node;
   const uint32_t n_start = (uint32_t)__popcll(__ballot(node != PT_END));
-  uint32_t t_eff = (n_start + round_div - 1u) / round_div;
+  uint32_t t_eff = ((n_start + round_div - 1u) * round_div_m16) >> 16;   // == (n_start + round_div - 1) / round_div (KParams::round_div_m16)
   if (t_eff > round_min) t_eff = round_min;
   if (t_eff < 1u) t_eff = 1u;
   if (STATS) w.alive = (uint32_t)__popcll(__ballot(1));
@@ -1180,7 +1310,7 @@ PT_DEV void traverse_round(const float4* nodes, const float4* tris, uint32_t n_n
     for (;;) {
       uint32_t leaf_first, leaf_count;
       walk_to_leaf_lds_state(state, lnk, w, leaf_first, leaf_count, walk_min);
-      if (leaf_count != 0u) walk_leaf<STATS>(tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters, small_det);
+      if (leaf_count != 0u) walk_leaf<STATS, true>(tris, w, leaf_first, leaf_count, cnt.tris, cnt.wave_tri_iters, small_det);
       if ((uint32_t)__popcll(__ballot(state != 0xFFFFu)) < t_eff) break;
     }
     w.node = walk_lds_node(lds_nodes, state);
@@ -1754,7 +1884,7 @@ PT_DEV uint32_t walk4q_visit(const float4* nodesq, const Stack4& stk, const Walk
 // MODE: 0 four-wide float nodes, 1 eight-wide quantised nodes, 2 four-wide quantised nodes
 template <bool STATS, int MODE = 0>
 PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4* tris, const Stack4& stk, f3 o, f3 d, Best& best, uint32_t& cur,
-                            uint32_t& sp, uint32_t round_min, uint32_t round_div, uint32_t walk_min, bool small_det, Counters& cnt)
+                            uint32_t& sp, uint32_t round_min, uint32_t round_div, uint32_t round_div_m16, uint32_t walk_min, bool small_det, Counters& cnt)
 {
   Walk w;
   walk_init(w, o, d, 1u);
@@ -1765,7 +1895,7 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
   if (MODE == 1) x8 = walk8_init(p, d);
   if (MODE == 2) x8.oct = (f_as_u(d.x) >> 31) | ((f_as_u(d.y) >> 31) << 1) | ((f_as_u(d.z) >> 31) << 2);
   const uint32_t n_start = (uint32_t)__popcll(__ballot(cur != PT_NONE));
-  uint32_t t_eff = (n_start + round_div - 1u) / round_div;
+  uint32_t t_eff = ((n_start + round_div - 1u) * round_div_m16) >> 16;   // == (n_start + round_div - 1) / round_div (KParams::round_div_m16)
   if (t_eff > round_min) t_eff = round_min;
   if (t_eff < 1u) t_eff = 1u;
   for (;;) {
@@ -1817,15 +1947,21 @@ PT_DEV void traverse_round4(const KParams& p, const float4* nodes4, const float4
 #pragma unroll
       for (uint32_t k = 0; k < 3u; ++k)
         if (k < count) { r[3 * k] = t[TS * k]; r[3 * k + 1] = t[TS * k + 1]; r[3 * k + 2] = t[TS * k + 2]; }
+      if (!STATS && PT_ASM_LEAF_WIDE && small_det) {   // (wave-uniform)
 #pragma unroll
-      for (uint32_t k = 0; k < 3u; ++k)
-        if (k < count) {
-          if (STATS) {
-            const unsigned long long act = __ballot(1);
-            if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) ++cnt.wave_tri_iters;
+        for (uint32_t k = 0; k < 3u; ++k)
+          if (k < count) mt_test_asm(r[3 * k], r[3 * k + 1], make_float2(r[3 * k + 2].x, r[3 * k + 2].y), w.o, w.d, w.best);
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k)
+          if (k < count) {
+            if (STATS) {
+              const unsigned long long act = __ballot(1);
+              if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)act) - 1)) ++cnt.wave_tri_iters;
+            }
+            mt_test<false>(r[3 * k], r[3 * k + 1], r[3 * k + 2], w.o, w.d, w.best, small_det);
           }
-          mt_test<false>(r[3 * k], r[3 * k + 1], r[3 * k + 2], w.o, w.d, w.best, small_det);
-        }
+      }
       if (STATS) cnt.tris += count < 3u ? count : 3u;
       if (count > 3u) walk_leaf<STATS>(tris, w, first + 3u, count - 3u, cnt.tris, cnt.wave_tri_iters, small_det, TS);
       cur = PT_POP_BATCH ? stack4_pop4(stk, sp, w.best.t) : stack4_pop(stk, sp, w.best.t);
@@ -2062,10 +2198,10 @@ pt_megakernel_restart(PT_KERNEL_PARAMS)
         if (STATS) cnt.tris += p.n_bvh_tris;
         node = PT_END;
       } else if (WIDE) {
-        traverse_round4<STATS, VARIANT == PT_RS_WIDE8 ? 1 : (VARIANT == PT_RS_WIDE4Q ? 2 : 0)>(p, p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.walk_min4, p.small_det != 0u, cnt);
+        traverse_round4<STATS, VARIANT == PT_RS_WIDE8 ? 1 : (VARIANT == PT_RS_WIDE4Q ? 2 : 0)>(p, p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min, p.round_div, p.round_div_m16, p.walk_min4, p.small_det != 0u, cnt);
         node = cur == PT_NONE ? PT_END : 0u;
       } else {
-        traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.walk_min, p.small_det != 0u, cnt);
+        traverse_round<STATS, LDS_RESIDENT>(s_nodes, s_tris, p.n_nodes, st.o, st.d, best, node, p.round_min, p.round_div, p.round_div_m16, p.walk_min, p.small_det != 0u, cnt);
       }
       if (STATS) {   // fetch_events: rounds of this wave; fetch_rays: walks that completed in them
         if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) cnt.fetch_events++;
@@ -2570,7 +2706,7 @@ __global__ void __launch_bounds__(64) pt_trace_rays_wide_kernel(PT_KERNEL_PARAMS
   Best best;
   best.t = PT_MAX_DIST; best.u = best.v = 0.f; best.idx = PT_END;
   uint32_t cur = (live && p.n_nodes4) ? 0u : PT_NONE, sp = 0u;
-  if (live) traverse_round4<false, MODE>(p, p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1u, p.small_det != 0u, cnt);
+  if (live) traverse_round4<false, MODE>(p, p.nodes4, p.tris_bvh, stk, o, d, best, cur, sp, 1u, 64u, 1024u, 1u, p.small_det != 0u, cnt);
   if (!live) return;
   Nearest nr;
   nr.t = best.t; nr.u = best.u; nr.v = best.v; nr.idx = best.idx;

@@ -635,6 +635,7 @@ int do_launch(ptamd_context* ctx, const ptamd_launch* l_in, bool stats, bool lat
     }
     p.round_min = ctx->round_min;
     p.round_div = ctx->round_div;
+    p.round_div_m16 = (65536u + ctx->round_div - 1u) / ctx->round_div;
     p.walk_min = ctx->walk_min;
     p.walk_min4 = ctx->walk_min4;
     p.tiles_per_ticket = tiles_per_ticket;
