@@ -9,5 +9,8 @@
 // Only the path-tracing kernel is contracted: the resolve pass (accumulate, tonemap, store) is the exact one.
 #pragma clang fp contract(fast)
 #define PT_FMA_BUILD 1
+#ifndef PT_ASM_LEAF
+#define PT_ASM_LEAF 0   /* the hand-scheduled triangle test is the exact operation sequence: here the compiled, contracted one runs */
+#endif
 #define ptamd ptamd_fma
 #include "pt_kernels.hip"
