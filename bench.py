@@ -57,6 +57,7 @@ MAX_FRAMES_PER_LAUNCH = 4   # ptamd_api.cpp: kMaxFramesPerSlab — a batch of mo
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 N_SIMDS, CLOCK_GHZ, VALU_CYCLES = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles
 VALU_PEAK_GINST = N_SIMDS * CLOCK_GHZ / VALU_CYCLES   # 1228.8 G wave-instructions/s
+SCALAR_PEAK_GINST = (N_SIMDS // 4) * CLOCK_GHZ         # 614.4 G/s: one scalar instruction per clock per CU (measured 596 G/s at the clock a busy chip holds)
 
 
 def parse_args(argv=None):
@@ -407,6 +408,14 @@ def roofline_block(pmc, kernel_symbol, kern_ms, n_slots, samples_per_launch, com
         # launch's 1/concurrent_launches of the GPU
         "valu_busy_at_measured_clock": None if (pmc is None or not g("gui_active_cycles_per_launch") or not g("valu_insts_per_launch"))
         else round(g("valu_insts_per_launch") * VALU_CYCLES * n_slots / (N_SIMDS * g("gui_active_cycles_per_launch")), 4),
+        # the CU's ONE scalar unit (SALU + branches; one instruction per clock per CU = half the VALU rate of its four SIMDs, measured:
+        # scripts/ubench/ifetch_rate.hip, profiles/r04_issue_ubench_*.txt) — the second issue roof of divergent compiled code
+        "scalar_issue": None if (pmc is None or g("salu_insts_per_launch") is None) else {
+            "salu_insts_per_launch": int(g("salu_insts_per_launch")),
+            "branch_insts_per_launch": None if g("branch_insts_per_launch") is None else int(g("branch_insts_per_launch")),
+            "achieved": round((g("salu_insts_per_launch") + (g("branch_insts_per_launch") or 0.0)) * per_s, 2),
+            "peak": SCALAR_PEAK_GINST, "unit": "G wave-inst/s",
+            "frac": round((g("salu_insts_per_launch") + (g("branch_insts_per_launch") or 0.0)) * per_s / SCALAR_PEAK_GINST, 4)},
         "pmc_source": g("source"), "build_id": build_id, "pmc_stale": stale,
         "peak_note": f"{N_SIMDS} SIMDs x {CLOCK_GHZ} GHz / {VALU_CYCLES} cycles per wave64 VALU instruction "
                      "(MI355X_MICROARCH.md: v_fma_f32 2 cyc on SIMD-32; 64 lanes x 2 flop x this = the 157.3 TFLOP/s FP32 vector peak)",

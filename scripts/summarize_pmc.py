@@ -80,7 +80,7 @@ rec = {"build_id": _native.load().ptamd_build_id().decode(), "kernel": kernel, "
        "frames_per_launch": fpl, "samples_per_launch": samples,
        "valu_insts_per_launch": res.get("SQ_INSTS_VALU"), "valu_insts_per_sample": d.get("valu_insts_per_sample"),
        "active_lanes": d.get("valu_active_lanes_per_inst(of 64)"),
-       "salu_insts_per_launch": res.get("SQ_INSTS_SALU"), "lds_insts_per_launch": res.get("SQ_INSTS_LDS"),
+       "salu_insts_per_launch": res.get("SQ_INSTS_SALU"), "branch_insts_per_launch": res.get("SQ_INSTS_BRANCH"), "lds_insts_per_launch": res.get("SQ_INSTS_LDS"),
        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = shader clocks the dispatch was resident for (MI355X_MICROARCH.md, DVFS)
        "gui_active_cycles_per_launch": None if "GRBM_GUI_ACTIVE" not in res else res["GRBM_GUI_ACTIVE"] / 8.0,
        "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
