@@ -1170,3 +1170,38 @@ def test_walk_only_queue_kernel_equals_the_brute_force_oracle(P, O, gpu_ctx):
                 gpu_ctx.trace_rays_queue(sid, r, out, config, refill)
                 torch.cuda.synchronize()
                 np.testing.assert_array_equal(out.cpu().numpy(), want, err_msg=f"n={n} config={config} refill={refill}")
+
+
+def test_coincident_triangles_resolve_to_the_lowest_face_index(P, O, gpu_ctx):
+    """The (t, face index) rule where it is exercised on every hit: each triangle of a soup stored three times, the copies scattered
+    through the face list (so that the walk meets them in any order and in different leaves), each copy with a material of its own —
+    the image shows which copy won.  The reference tests faces in storage order and keeps the first of equal distances
+    (intersection.cuh:128 `t < best`): the lowest index.  Covers the hand-scheduled triangle test's unsigned-compare form of the rule
+    (mt_test_asm) in the LDS-resident kernels, the compiled form in the others, and the wide walk (900 faces do not fit in LDS)."""
+    rng = np.random.default_rng(77)
+    for n_base, extent in ((40, 1.2), (300, 2.5)):
+        base = random_soup(rng, n_base, extent=extent, size=0.9 if n_base == 40 else 0.4)
+        order = rng.permutation(3 * n_base)
+        tris = np.concatenate([base, base, base])[order]
+        copy_of = (np.arange(3 * n_base) // n_base)[order]                      # which copy a face is: its material
+        tex = [np.float32([[[0.9, 0.1, 0.1, 0.2]]]), np.float32([[[0.1, 0.9, 0.1, 0.0]]]), np.float32([[[0.1, 0.1, 0.9, 0.4]]])]
+        hs = make_scene(P, tris, materials=[(0, -1, 1.0), (1, -1, 1.0), (2, -1, 1.0)], material_ids=copy_of, textures=tex,
+                        lights=[((0.0, 2.0, 1.0), (1, 1, 1), 5.0, 0.5)])
+        cube = synthetic_cubemap(rng, 2)
+        osc = O.OracleScene.from_host_scene(hs, cube)
+        rays = random_rays(rng, 20000, extent=extent)
+        want = O.intersect(osc, rays)
+        hit = want[:, 0] == 1
+        assert hit.sum() > 2000
+        # every hit names the first stored copy of its triangle
+        first_copy = {}
+        for f, key in enumerate(map(bytes, tris.reshape(len(tris), -1))):
+            first_copy.setdefault(key, f)
+        assert all(first_copy[tris[f].tobytes()] == f for f in np.unique(want[hit, 1]))
+        sid = gpu_ctx.upload_scene(hs)
+        for k in (P.KERNEL_BVH, P.KERNEL_BRUTE_FORCE, P.KERNEL_BVH_RESTART):
+            np.testing.assert_array_equal(gpu_ctx.trace_rays(sid, rays, k), want)
+        ref = O.render(osc, O.camera_from_record(hs.camera), 96, 64, spp=2, bounces=4)
+        for kernel in KERNELS:
+            acc, rgba = gpu_render(P, gpu_ctx, hs, cube, 96, 64, 2, 4, kid(P, kernel))
+            assert_same(acc, rgba, *ref, f"coincident triangles x3, {3 * n_base} faces, {kernel}")
