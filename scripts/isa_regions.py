@@ -8,9 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cuda-pathtracer_amd", "csrc", "pt_kernels.hip")
 MARKS = [  # (unique source anchor, marker name) — the marker goes in front of the anchor
     ("    if (!idle) {\n      if (!walking) {\n        best.t = PT_MAX_DIST;", "round_begin"),
-    ("      if (WIDE) {\n        traverse_round4<STATS>(p.nodes4, s_tris, stk, st.o, st.d, best, cur, sp, p.round_min", "traverse_begin"),
+    ("      } else if (WIDE) {\n        traverse_round4<STATS, VARIANT == PT_RS_WIDE8", "traverse_begin"),
     ("      if (node == PT_END) {\n        // the iteration's first variate", "traverse_end"),
-    ("        walking = false;\n        if (path_post<STATS>(p, st, r1, n, cnt)) {", "lights_end"),
+    ("        if (path_post<STATS>(p, st, r1, n, cnt)) {\n          path_finish_sample(p, st);", "lights_end"),
     ("          path_finish_sample(p, st);\n          idle = true;\n          if (STATS) samples++;", "post_end"),
     ("  if (!p.is_static) {\n    st.acc = found ? inter.diffuse_col : env_lookup(p, st.d);", "resolve_end"),
     ("  const f3 d = st.d;\n  const float cos_theta = dot(inter.normal, d);", "miss_end"),
@@ -28,7 +28,7 @@ with tempfile.TemporaryDirectory() as td:
                            "-I" + os.path.join(ROOT, "cuda-pathtracer_amd", "csrc"), "-x", "hip", "--cuda-device-only", "-S", "-o", out, src],
                           stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-start = [i for i, l in enumerate(lines) if l.startswith("_ZN5ptamd21pt_megakernel_restartILb1ELb0EEEvNS_7KParamsE:")][0]
+start = [i for i, l in enumerate(lines) if l.startswith("_ZN5ptamd21pt_megakernel_restartILb1ELi0EEEvNS_7KParamsE:")][0]
 end = [i for i, l in enumerate(lines) if i > start and re.match(r"\.Lfunc_end\d+:", l)][0]
 marks = [(i, re.search(r"; PT_MARK (\w+)", lines[i]).group(1)) for i in range(start, end) if "; PT_MARK" in lines[i]]
 bounds = [(start, "prologue")] + marks + [(end, "end")]
