@@ -117,6 +117,7 @@ struct ptamd_context {
   bool wide4q = false;                    // PTAMD_WIDE4Q=1 (tuning): big scenes walk the 64-byte quantised four-wide nodes instead of the float ones (ahead by 2.8 % while the walk's LDS accesses went out as FLAT instructions, level since they are LDS instructions: profiles/r03_notes.md)
   bool wide8 = false;                     // PTAMD_WIDE8=1 (tuning): big scenes walk the eight-wide quantised nodes (measured 8 % slower: DESIGN.md §4)
   uint2* d_trace_spill = nullptr;             // ptamd_trace_rays_queue: global continuation of the walk-only kernel's stacks (grown on demand)
+  struct { uint32_t config = ~0u; size_t lds = 0; int resident = 0; } trace_queue_cache;   // ... its last configuration: dynamic-LDS attribute set, blocks resident per CU
   size_t trace_spill_bytes = 0;
   unsigned long long* d_timeline = nullptr;   // ptamd_set_timeline: 4 time stamps per wave of the restart kernel
   uint32_t timeline_waves = 0;
@@ -1172,7 +1173,7 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel, con
 int ptamd_trace_rays_queue(ptamd_context* ctx, uint32_t scene_id, const float* rays_dev, uint32_t n, int32_t* out_dev, uint32_t config,
                            uint32_t refill_min, void* stream, uint32_t* out_waves_per_cu)
 {
-  if (!ctx || scene_id >= ctx->scenes.size() || (n && (!rays_dev || !out_dev)) || config > 3u) { set_error("ptamd_trace_rays_queue: bad argument"); return PTAMD_ERR_ARG; }
+  if (!ctx || scene_id >= ctx->scenes.size() || (n && (!rays_dev || !out_dev)) || config > 3u || n >= 0x80000000u) { set_error("ptamd_trace_rays_queue: bad argument"); return PTAMD_ERR_ARG; }
   if (n == 0) return PTAMD_OK;
   PT_HIP(hipSetDevice(ctx->device));
   const DeviceScene& s = ctx->scenes[scene_id];
@@ -1211,7 +1212,7 @@ int ptamd_trace_rays_queue(ptamd_context* ctx, uint32_t scene_id, const float* r
   uint32_t* head = reinterpret_cast<uint32_t*>(ctx->d_stats + 28);
   PT_HIP(hipMemsetAsync(head, 0, sizeof(uint32_t), st));
   // (the occupancy query costs the host a millisecond: once per configuration and LDS size)
-  static thread_local struct { uint32_t config = ~0u; size_t lds = 0; int resident = 0; } cache;
+  auto& cache = ctx->trace_queue_cache;   // (per context: the attribute and the answer belong to this context's device)
   const bool cached = cache.config == config && cache.lds == lds;
   int resident = cache.resident;
   hipError_t e = launch_trace_queue(p, config, lds, n_blocks, rays_dev, n, reinterpret_cast<int4*>(out_dev), head, cached ? nullptr : &resident, st);

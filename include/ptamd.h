@@ -373,7 +373,9 @@ int ptamd_trace_rays(ptamd_context* ctx, uint32_t scene_id, uint32_t kernel,
  * taking its next ray as soon as `refill_min` lanes of its wave are idle.  No path state in registers, so the same walk runs at
  * config 0: 16 waves per CU (4 per SIMD), 512-node LDS treelet; 1: 20 waves (5 per SIMD), two workgroups with 256 nodes each;
  * 2: 24 waves (6 per SIMD), 256 nodes each; 3: 16 waves, 256 nodes.  Asynchronous on `stream`; rays_dev / out_dev are device
- * pointers; *out_waves_per_cu = waves resident per CU (occupancy query).  scripts/gpu_trace_queue.py, profiles/r04_notes.md. */
+ * pointers; *out_waves_per_cu = waves resident per CU (occupancy query).  The queue head and the stack continuation belong to the
+ * context: calls on ONE context must be ordered (one stream, or an event between streams); n < 2^31.
+ * scripts/gpu_trace_queue.py, profiles/r04_notes.md. */
 int ptamd_trace_rays_queue(ptamd_context* ctx, uint32_t scene_id, const float* rays_dev, uint32_t n, int32_t* out_dev, uint32_t config,
                            uint32_t refill_min, void* stream, uint32_t* out_waves_per_cu);
 
