@@ -25,6 +25,12 @@ if [ "$PMC_EXTRA" = "ifetch" ]; then
         "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQC_ICACHE_BUSY_CYCLES SQC_ICACHE_INPUT_VALID_READYB SQC_TC_INST_REQ SQC_TC_STALL" \
         "SQ_IFETCH_LEVEL SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM GRBM_GUI_ACTIVE")
 fi
+# PMC_EXTRA=tcp: busy clocks of the vector L1 (gate enable) and its tag lookups.  (A second pass with the stall counters
+# TCP_TCP_TA_DATA_STALL_CYCLES / TCP_TCR_TCP_STALL_CYCLES / TCP_TD_TCP_STALL_CYCLES / TCP_READ_TAGCONFLICT_STALL_CYCLES hung rocprofv3
+# on this pool in round 4, as the TA_* set does: do not add them.)
+if [ "$PMC_EXTRA" = "tcp" ]; then
+  SETS=("GRBM_GUI_ACTIVE TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum")
+fi
 if [ "$PMC_EXTRA" = "l1" ]; then
   SETS+=("TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" \
          "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum")
